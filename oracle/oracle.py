@@ -1,0 +1,231 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy binding of the CPU restatements in oracle/*.c (liboracle.so).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (pulselib_amd/) never does.
+
+`OraclePokerEnv` mirrors the state names of the reference's
+environments/Poker/PokerGPU.py (numpy arrays instead of torch tensors) so parity tests can compare
+attribute by attribute.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+HR_LEN = 32487834
+ACTIVE, FOLDED, ALLIN, SITOUT = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "liboracle.so"
+    srcs = [_HERE / "handranks_oracle.c", _HERE / "poker_oracle.c", _HERE / "envs_oracle.c"]
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-C", str(_HERE), "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        _LIB.hr_oracle_generate.restype = C.c_int
+        _LIB.oracle_reward.restype = C.c_float
+        _LIB.oracle_step_table.restype = C.c_float
+        _LIB.oracle_select_action_epsilon_greedy.restype = C.c_int32
+    return _LIB
+
+
+_HR_CACHE = None
+
+
+def hand_ranks(cache_path: str | None = None) -> np.ndarray:
+    """The oracle's own HandRanks table (int32[32,487,834]); generated once per process, optionally
+    cached on disk (default: $PULSE_ORACLE_HR or /tmp/pulse_oracle_HandRanks.dat)."""
+    global _HR_CACHE
+    if _HR_CACHE is not None:
+        return _HR_CACHE
+    path = Path(cache_path or os.environ.get("PULSE_ORACLE_HR", "/tmp/pulse_oracle_HandRanks.dat"))
+    if path.exists() and path.stat().st_size == HR_LEN * 4:
+        _HR_CACHE = np.fromfile(path, dtype=np.int32)
+        return _HR_CACHE
+    out = np.zeros(HR_LEN, dtype=np.int32)
+    rc = lib().hr_oracle_generate(out.ctypes.data_as(C.c_void_p))
+    if rc != 612977:
+        raise RuntimeError(f"hr_oracle_generate failed: {rc}")
+    try:
+        tmp = path.with_suffix(f".tmp{os.getpid()}")
+        out.tofile(tmp)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    _HR_CACHE = out
+    return out
+
+
+class _PokerStruct(C.Structure):
+    _fields_ = (
+        [("n_games", C.c_int32), ("n_players", C.c_int32), ("active_players", C.c_int32), ("obs_size", C.c_int32),
+         ("hr_len", C.c_int64), ("hand_ranks", C.c_void_p)]
+        + [(n, C.c_void_p) for n in (
+            "pots", "stages", "deck_positions", "button", "sb", "bb", "idx", "highest", "agg", "acted",
+            "last_raise_size", "prev_stacks", "prev_invested", "raise_amounts",
+            "is_done", "equity_dirty", "is_round_over",
+            "stacks", "current_round_bet", "total_invested", "status", "hands", "board", "decks",
+            "equities", "obs")]
+        + [("w1", C.c_float), ("w2", C.c_float), ("K", C.c_int32), ("alpha", C.c_int32)]
+    )
+
+
+_SCALARS_I32 = ("pots", "stages", "deck_positions", "button", "sb", "bb", "idx", "highest", "agg", "acted",
+                "last_raise_size", "prev_stacks", "prev_invested", "raise_amounts")
+_SCALARS_U8 = ("is_done", "equity_dirty", "is_round_over")
+_ROWS = ("stacks", "current_round_bet", "total_invested", "status")
+
+INT_STATE = _SCALARS_I32 + _SCALARS_U8 + _ROWS + ("hands", "board", "decks")
+
+
+class OraclePokerEnv:
+    """Numpy twin of the reference PokerGPU (PokerGPU.py:8-633) over liboracle.so."""
+
+    NUM_ACTIONS = 13
+    ACTIVE, FOLDED, ALLIN, SITOUT = 0, 1, 2, 3
+
+    def __init__(self, n_players=6, max_players=10, n_games=100, starting_bbs=100, max_bbs=1000,
+                 w1=.5, w2=.5, K=20, alpha=300, hand_ranks_table: np.ndarray | None = None, n_threads: int = 1):
+        self.n_players, self.max_players, self.n_games = n_players, max_players, n_games
+        self.starting_bbs, self.max_bbs = starting_bbs, max_bbs
+        self.w1, self.w2, self.K, self.alpha = float(np.float32(w1)), float(np.float32(w2)), int(K), int(alpha)
+        self.obs_size = 13 + (max_players - 1) * 3
+        self.hand_ranks = hand_ranks() if hand_ranks_table is None else np.ascontiguousarray(hand_ranks_table, dtype=np.int32)
+        self.n_threads = n_threads
+        self.active_players = n_players
+        self._first = True
+        N, P = n_games, n_players
+        for n in _SCALARS_I32:
+            setattr(self, n, np.zeros(N, dtype=np.int32))
+        for n in _SCALARS_U8:
+            setattr(self, n, np.zeros(N, dtype=np.uint8))
+        for n in _ROWS:
+            setattr(self, n, np.zeros((N, P), dtype=np.int32))
+        self.hands = np.full((N, P, 2), -1, dtype=np.int32)
+        self.board = np.full((N, 5), -1, dtype=np.int32)
+        self.decks = np.zeros((N, 52), dtype=np.int32)
+        self.equities = np.full((N, P), .5, dtype=np.float32)
+        self.obs = np.zeros((N, self.obs_size), dtype=np.float32)
+        self.rewards = np.zeros(N, dtype=np.float32)
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _struct(self) -> _PokerStruct:
+        s = _PokerStruct()
+        s.n_games, s.n_players, s.active_players, s.obs_size = self.n_games, self.n_players, self.active_players, self.obs_size
+        s.hr_len = self.hand_ranks.size
+        s.hand_ranks = self.hand_ranks.ctypes.data
+        for n in _SCALARS_I32 + _SCALARS_U8 + _ROWS + ("hands", "board", "decks", "equities", "obs"):
+            a = getattr(self, n)
+            assert a.flags["C_CONTIGUOUS"], n
+            setattr(s, n, a.ctypes.data)
+        s.w1, s.w2, s.K, s.alpha = self.w1, self.w2, self.K, self.alpha
+        return s
+
+    # -- reference surface --------------------------------------------------------------------
+    def reset(self, options=None, rng: np.random.Generator | None = None):
+        """PokerGPU.py:73-157.  `options["active_players"]` may be an int here to force A (the
+        reference samples it with torch.randint); True samples 2..n_players from `rng`."""
+        options = options or {}
+        ap = options.get("active_players", False)
+        if ap is True:
+            cand = int((rng or np.random.default_rng()).integers(2, self.n_players + 1))
+        elif ap:
+            cand = int(ap)
+        else:
+            cand = self.n_players
+        q_seat = options.get("q_agent_seat", 0)
+        self.active_players = max(cand, q_seat + 1)
+        decks = options.get("prefixed_decks")
+        if decks is None:
+            raise ValueError("the oracle needs prefixed_decks (RNG is injected)")
+        decks = np.asarray(decks, dtype=np.int32)
+        if decks.shape != (self.n_games, 52):
+            raise ValueError(f"prefixed_decks must have shape {(self.n_games, 52)}, got {tuple(decks.shape)}")
+        self.decks = np.ascontiguousarray(decks).copy()
+        rotation = int(options.get("rotation", 0))
+        A = self.active_players
+        if self._first:
+            buttons = np.zeros(self.n_games, dtype=np.int32)
+        else:
+            buttons = ((self.button + 1) % A).astype(np.int32)
+        self.equities = np.full((self.n_games, A), .5, dtype=np.float32)
+        s = self._struct()
+        lib().oracle_reset(C.byref(s), C.c_int(1 if self._first else 0), C.c_int(self.starting_bbs), C.c_int(self.max_bbs),
+                           C.c_int(rotation), buttons.ctypes.data_as(C.c_void_p), C.c_int(self.n_threads))
+        self._first = False
+        return self.obs, {"active_players": A, "stacks": self.stacks, "seat_idx": self.idx}
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int64)
+        assert actions.shape == (self.n_games,)
+        s = self._struct()
+        lib().oracle_step(C.byref(s), actions.ctypes.data_as(C.c_void_p), self.rewards.ctypes.data_as(C.c_void_p),
+                          C.c_int(self.n_threads))
+        return self.obs, self.rewards, self.is_done.astype(bool), np.zeros(self.n_games, dtype=bool), \
+            {"active_players": self.active_players, "stacks": self.stacks, "seat_idx": self.idx}
+
+    # per-table method-level entry points for white-box checks
+    def _each(self, fn, *extra):
+        s = self._struct()
+        for t in range(self.n_games):
+            fn(C.byref(s), C.c_int(t), *extra)
+
+    def get_obs(self):
+        self._each(lib().oracle_get_obs)
+        return self.obs
+
+    def calculate_equities(self):
+        self._each(lib().oracle_calculate_equities)
+
+    def execute_actions(self, actions):
+        s = self._struct()
+        for t in range(self.n_games):
+            lib().oracle_execute_actions(C.byref(s), C.c_int(t), C.c_int64(int(actions[t])))
+
+    def resolve_fold_winners(self):
+        s = self._struct()
+        for t in range(self.n_games):
+            lib().oracle_resolve_fold_winner(C.byref(s), C.c_int(t), C.c_int(int(self.is_done[t])))
+
+    def resolve_terminated_games(self):
+        s = self._struct()
+        for t in range(self.n_games):
+            lib().oracle_resolve_terminated(C.byref(s), C.c_int(t), C.c_int(int(self.is_done[t])))
+
+    def post_blinds(self):
+        self._each(lib().oracle_post_blinds)
+
+    def snapshot(self) -> dict:
+        d = {n: getattr(self, n).copy() for n in INT_STATE}
+        d["equities"] = self.equities.copy()
+        d["obs"] = self.obs.copy()
+        return d
+
+
+def eval_hands(hr: np.ndarray, cards: np.ndarray) -> np.ndarray:
+    """5/6/7-card lookups exactly as PokerGPU.py:437-444 / :500 / :521 walk the table."""
+    cards = np.ascontiguousarray(cards, dtype=np.int32)
+    out = np.zeros(cards.shape[0], dtype=np.int32)
+    lib().oracle_eval_hands(hr.ctypes.data_as(C.c_void_p), C.c_int64(hr.size), cards.ctypes.data_as(C.c_void_p),
+                            C.c_int(cards.shape[0]), C.c_int(cards.shape[1]), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def philox4x32(seed: int, subseq: int, offset: int) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_philox4x32(C.c_uint64(seed), C.c_uint64(subseq), C.c_uint64(offset), out.ctypes.data_as(C.c_void_p))
+    return out
