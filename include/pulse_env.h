@@ -1,0 +1,173 @@
+/*
+ * pulse_env.h -- C ABI of libpulse_hip.so, the MI355X (gfx950) batched env-step engine.
+ *
+ * Drop-in boundary for the hot path of cerredz/Pulselib: each entry point replaces one chain of
+ * eager torch ops in the reference (file:line given per function, relative to the reference
+ * checkout).  Plain pointers and sizes only; all device buffers are allocated and owned by the
+ * caller (PyTorch-ROCm in the shipped host code, anything else that can hand out HBM pointers
+ * works too).  Every launch is enqueued on the caller's hipStream_t and returns without a host
+ * sync.  Return value: 0 on success, negative PULSE_E* on error (message: pulse_last_error()).
+ * The library never throws across this boundary and keeps no per-call device allocations.
+ *
+ * There is no CPU fallback: without a usable HIP device the launch functions return
+ * PULSE_ENODEVICE.  (pulse_handranks_generate is a host-side data-file builder, not a fallback.)
+ */
+#ifndef PULSE_ENV_H
+#define PULSE_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PULSE_ABI_VERSION 1
+
+#define PULSE_EINVAL    (-1)   /* bad argument (shape / null pointer / unsupported size)            */
+#define PULSE_ENODEVICE (-2)   /* no HIP device / HIP runtime error before launch                   */
+#define PULSE_ELAUNCH   (-3)   /* hipLaunchKernel / hipGetLastError reported an error               */
+#define PULSE_EINTERNAL (-4)
+
+#define PULSE_HANDRANKS_LEN 32487834   /* int32 entries of HandRanks.dat (PokerGPU.py:51-57)        */
+#define PULSE_MAX_SEATS     16         /* seats per table the kernels support (reference default 10) */
+
+/* Seat status codes, environments/Poker/PokerGPU.py:11 */
+enum { PULSE_ACTIVE = 0, PULSE_FOLDED = 1, PULSE_ALLIN = 2, PULSE_SITOUT = 3 };
+
+/* Agent types for pulse_poker_policy, environments/Poker/utils.py:80-87 (+ Player.py:79-176) */
+enum {
+    PULSE_AGENT_EXTERNAL = 0,        /* seat is played by the caller (Q-network): action left untouched */
+    PULSE_AGENT_RANDOM = 1,          /* utils.py:121                 */
+    PULSE_AGENT_HEURISTIC_HANDS = 2, /* Player.py:79-104             */
+    PULSE_AGENT_TIGHT_AGGRESSIVE = 3,/* Player.py:106-126            */
+    PULSE_AGENT_LOOSE_PASSIVE = 4,   /* Player.py:128-151            */
+    PULSE_AGENT_SMALL_BALL = 5       /* Player.py:153-176            */
+};
+
+/*
+ * Device view of one PokerGPU instance: the reference's own SoA tensors
+ * (environments/Poker/PokerGPU.py:81-155), row-major, device pointers.
+ *   [N]      int32 : pots stages deck_positions button sb bb idx highest agg acted
+ *                    last_raise_size prev_stacks prev_invested
+ *   [N]      uint8 : is_done (torch.bool), equity_dirty (torch.bool)
+ *   [N,P]    int32 : stacks current_round_bet total_invested status
+ *   [N,P,2]  int32 : hands          [N,5] int32 : board        [N,52] int32 : decks (cards 1..52)
+ *   [N,A]    fp32  : equities       [N,obs_size] fp32 : obs (obs_size = 13 + 3*(max_players-1))
+ *   hand_ranks: int32[hand_ranks_len], the 2+2 table (PokerGPU.py:47-58)
+ *   w1,w2 (fp32) K,alpha (int32): 0-d device tensors, read by the kernel at every step because
+ *   callers re-assign them (tests/poker/test_poker_gpu_round_progression.py:207-210).
+ * is_done_out may alias is_done (in-place) or be a second buffer (the host code ping-pongs two so
+ * that the tensor returned by step() is not rewritten by the next step, as in PokerGPU.py:619-623).
+ */
+typedef struct PulsePokerView {
+    int32_t n_games, n_players, active_players, max_players;
+    int32_t obs_size, hand_ranks_len;
+    const int32_t* hand_ranks;
+    int32_t *pots, *stages, *deck_positions, *button, *sb, *bb, *idx, *highest, *agg, *acted,
+            *last_raise_size, *prev_stacks, *prev_invested;
+    uint8_t *is_done, *is_done_out, *equity_dirty;
+    int32_t *stacks, *current_round_bet, *total_invested, *status;
+    int32_t *hands, *board;
+    const int32_t* decks;
+    float *equities, *obs;
+    const float *w1, *w2;
+    const int32_t *K, *alpha;
+} PulsePokerView;
+
+/* Phase bits for pulse_poker_phases: the white-box methods the reference's tests call directly. */
+#define PULSE_PH_CAPTURE   0x001u  /* PokerGPU.py:530-539  prev_done / actor / prev_stacks / prev_invested */
+#define PULSE_PH_EQUITY    0x002u  /* PokerGPU.py:455-525  calculate_equities                             */
+#define PULSE_PH_EXECUTE   0x004u  /* PokerGPU.py:230-303  execute_actions                                */
+#define PULSE_PH_ADVANCE   0x008u  /* PokerGPU.py:547-616  next actor, round close, street transition     */
+#define PULSE_PH_FOLDWIN   0x010u  /* PokerGPU.py:331-338  resolve_fold_winners                           */
+#define PULSE_PH_SHOWDOWN  0x020u  /* PokerGPU.py:380-453  resolve_terminated_games + :340-378 side pots  */
+#define PULSE_PH_CLEARDONE 0x040u  /* PokerGPU.py:625-628                                                 */
+#define PULSE_PH_REWARD    0x080u  /* PokerGPU.py:305-329,:631-632 poker_reward_gpu                       */
+#define PULSE_PH_OBS       0x100u  /* PokerGPU.py:159-179  get_obs                                        */
+#define PULSE_PH_STEP      0x1FFu  /* all of the above in reference order = PokerGPU.step :527-633        */
+
+int pulse_version(void);
+const char* pulse_last_error(void);
+
+/* Host: build the 2+2 table (replaces the HandRanks.dat download, PokerGPU.py:47-58).
+ * out = host int32[PULSE_HANDRANKS_LEN].  Deterministic; n_threads<=0 = all cores. */
+int pulse_handranks_generate(int32_t* out, int n_threads);
+
+/* Standalone 5/6/7-card lookup kernel (PokerGPU.py:437-444, :497-500, :518-521):
+ * cards device int32[n_hands,n_cards]; out device int32[n_hands]; n_cards 7 -> raw chain value,
+ * 6 -> HR[p], 5 -> HR[p] (flop_double=0) or HR[HR[p]] (flop_double=1). */
+int pulse_poker_eval_hands(const int32_t* hand_ranks, int32_t hand_ranks_len, const int32_t* cards,
+                           int32_t n_hands, int32_t n_cards, int32_t flop_double, int32_t* out, void* stream);
+
+/* PokerGPU.step (PokerGPU.py:527-633), one fused launch.  actions device int64[N] (any value; <0 =
+ * no-op, >12 = raise of 0 as in the reference's masks), rewards device fp32[N] out. */
+int pulse_poker_step(const PulsePokerView* v, const int64_t* actions, float* rewards, void* stream);
+
+/* Run a subset of step()'s phases in reference order (white-box methods).  For FOLDWIN/SHOWDOWN
+ * without CAPTURE the "newly done" mask is is_done itself, as in PokerGPU.py:333,386.  actor_idx
+ * (device int32[N]) is used by REWARD when CAPTURE is absent (PokerGPU.py:305), else NULL. */
+int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* actions,
+                       const int32_t* actor_idx, float* rewards, void* stream);
+
+/* PokerGPU.reset (PokerGPU.py:73-157) after the host picked active_players (v->active_players).
+ *   first          : 1 = no previous episode (stacks := starting_bbs, button := 0)           (:101-102,:121)
+ *   prefixed_decks : device int32[N,52] copied into v->decks, or NULL = shuffle on device with
+ *                    Philox4x32-10(seed, table id + table_id0, episode) (replaces rand().argsort, :86)
+ *   decks_out      : v->decks is const in the view; reset writes through this pointer.
+ *   rotation       : torch.roll shift of the stack rows                                     (:104-110) */
+typedef struct PulsePokerResetOpts {
+    int32_t first, starting_bbs, max_bbs, rotation;
+    uint64_t seed, episode, table_id0;
+    const int32_t* prefixed_decks;
+    int32_t* decks_out;
+} PulsePokerResetOpts;
+int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream);
+
+/* build_actions + scripted opponents (environments/Poker/utils.py:108-123, Player.py:79-176):
+ * obs device fp32[n,obs_stride] (columns 5,6 = hole cards, 9 = pot), seat_idx device int32[n] (the
+ * `curr_players` argument).  For every table whose seat has a scripted type, actions[t] is written;
+ * EXTERNAL seats are left untouched.  agent_types: host uint8[n_players] (PULSE_AGENT_*).
+ * Random draws: Philox4x32-10(seed, table id + table_id0, step_counter). */
+int pulse_poker_policy(const float* obs, int32_t obs_stride, const int32_t* seat_idx, int32_t n,
+                       const uint8_t* agent_types, int32_t n_players, uint64_t seed, uint64_t step_counter,
+                       uint64_t table_id0, int64_t* actions, void* stream);
+
+/* Fused roll-out step for scripted tables: policy (above) + step in ONE launch; actions[] is both
+ * input (EXTERNAL seats) and output (what was played).  Same results as policy followed by step. */
+int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
+                            uint64_t table_id0, int64_t* actions, float* rewards, void* stream);
+
+/* Episode statistics for the trainer's stop rule and returns (scripts/Poker/trainGPU.py:27-33,96):
+ * stats device int64[2] += {#tables with is_done, 0}; fstats device double[1] += sum(rewards[mask]). */
+int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n,
+                      int64_t* stats, double* fstats, void* stream);
+
+/* ---- Blackjack (environments/blackjack/blackjack.py) ------------------------------------------ */
+typedef struct PulseBlackjackView {
+    int32_t batch_size;
+    const int32_t* decks;              /* [B,52] cards 0..51 (blackjack.py:24-29)                  */
+    int32_t *deck_positions, *players_cards, *players_card_idx, *player_card_sums;
+    int32_t *dealer_cards, *dealer_card_idx, *dealer_upcard, *dealer_card_sums;
+    uint8_t *terminated, *has_ace, *dealer_has_ace;
+    int32_t *rewards, *obs;            /* obs [B,3] int32                                          */
+} PulseBlackjackView;
+/* reset: decks_src NULL = device shuffle Philox(seed, game id, episode), else copied (blackjack.py:23-101) */
+int pulse_blackjack_reset(const PulseBlackjackView* v, const int32_t* decks_src, int32_t* decks_out,
+                          uint64_t seed, uint64_t episode, void* stream);
+int pulse_blackjack_step(const PulseBlackjackView* v, const int64_t* actions, void* stream);   /* :113-186 */
+
+/* ---- 2048 (environments/2048/TFE.py), batched: boards device int32[B,n,n] ---------------------- */
+int pulse_tfe_reset(int32_t* boards, int64_t* total_score, int32_t n_boards, int32_t n, uint64_t seed,
+                    uint64_t board_id0, void* stream);                                          /* :143-149 */
+int pulse_tfe_step(int32_t* boards, int64_t* total_score, const int64_t* actions, int32_t* rewards,
+                   uint8_t* dones, int32_t n_boards, int32_t n, uint64_t seed, uint64_t board_id0,
+                   uint64_t step_counter, void* stream);                                        /* :152-189 */
+
+/* ---- Particle2D (environments/Particle2D/Particle2D.py:22-30) ---------------------------------- */
+int pulse_particle2d_step(float* state, const float* action, int32_t* steps, float* obs_out, float* rewards,
+                          uint8_t* terminated, int32_t n, float dt, int32_t max_steps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PULSE_ENV_H */

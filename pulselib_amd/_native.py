@@ -1,0 +1,120 @@
+"""ctypes binding of libpulse_hip.so (include/pulse_env.h).
+
+The library is the product: if it is missing or does not load, importing this module's `lib()`
+raises -- there is no PyTorch/CPU fallback for any environment step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_SO = _PKG / "libpulse_hip.so"
+_CSRC = _PKG / "csrc"
+_LIB: C.CDLL | None = None
+
+HANDRANKS_LEN = 32487834
+MAX_SEATS = 16
+
+# phase bits (include/pulse_env.h)
+PH_CAPTURE, PH_EQUITY, PH_EXECUTE, PH_ADVANCE = 0x001, 0x002, 0x004, 0x008
+PH_FOLDWIN, PH_SHOWDOWN, PH_CLEARDONE, PH_REWARD, PH_OBS = 0x010, 0x020, 0x040, 0x080, 0x100
+PH_STEP = 0x1FF
+
+AGENT_EXTERNAL, AGENT_RANDOM, AGENT_HEURISTIC_HANDS, AGENT_TIGHT_AGGRESSIVE, AGENT_LOOSE_PASSIVE, AGENT_SMALL_BALL = range(6)
+
+
+class PulseError(RuntimeError):
+    pass
+
+
+class PokerView(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("n_games", "n_players", "active_players", "max_players", "obs_size", "hand_ranks_len")]
+        + [(n, C.c_void_p) for n in (
+            "hand_ranks",
+            "pots", "stages", "deck_positions", "button", "sb", "bb", "idx", "highest", "agg", "acted",
+            "last_raise_size", "prev_stacks", "prev_invested",
+            "is_done", "is_done_out", "equity_dirty",
+            "stacks", "current_round_bet", "total_invested", "status",
+            "hands", "board", "decks", "equities", "obs",
+            "w1", "w2", "K", "alpha")]
+    )
+
+
+class PokerResetOpts(C.Structure):
+    _fields_ = [("first", C.c_int32), ("starting_bbs", C.c_int32), ("max_bbs", C.c_int32), ("rotation", C.c_int32),
+                ("seed", C.c_uint64), ("episode", C.c_uint64), ("table_id0", C.c_uint64),
+                ("prefixed_decks", C.c_void_p), ("decks_out", C.c_void_p)]
+
+
+class BlackjackView(C.Structure):
+    _fields_ = [("batch_size", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "decks", "deck_positions", "players_cards", "players_card_idx", "player_card_sums",
+        "dealer_cards", "dealer_card_idx", "dealer_upcard", "dealer_card_sums",
+        "terminated", "has_ace", "dealer_has_ace", "rewards", "obs")]
+
+
+# every symbol include/pulse_env.h declares: (restype, argtypes)
+_P, _I32, _U32, _U64, _F32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float
+SYMBOLS = {
+    "pulse_version": (C.c_int, []),
+    "pulse_last_error": (C.c_char_p, []),
+    "pulse_handranks_generate": (C.c_int, [_P, C.c_int]),
+    "pulse_poker_eval_hands": (C.c_int, [_P, _I32, _P, _I32, _I32, _I32, _P, _P]),
+    "pulse_poker_step": (C.c_int, [_P, _P, _P, _P]),
+    "pulse_poker_phases": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "pulse_poker_reset": (C.c_int, [_P, _P, _P]),
+    "pulse_poker_policy": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _U64, _U64, _U64, _P, _P]),
+    "pulse_poker_policy_step": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, _P]),
+    "pulse_poker_stats": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
+    "pulse_blackjack_reset": (C.c_int, [_P, _P, _P, _U64, _U64, _P]),
+    "pulse_blackjack_step": (C.c_int, [_P, _P, _P]),
+    "pulse_tfe_reset": (C.c_int, [_P, _P, _I32, _I32, _U64, _U64, _P]),
+    "pulse_tfe_step": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _U64, _U64, _U64, _P]),
+    "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
+}
+
+
+def build(force: bool = False) -> Path:
+    """Compile libpulse_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = list(_CSRC.glob("*.hip")) + list(_CSRC.glob("*.cpp")) + list(_CSRC.glob("*.h")) + [_PKG.parent / "include" / "pulse_env.h"]
+    if force or not _SO.exists() or any(s.stat().st_mtime > _SO.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-C", str(_CSRC)] + (["-B"] if force else []))
+    return _SO
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not _SO.exists():
+            if os.environ.get("PULSE_NO_AUTOBUILD"):
+                raise PulseError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+            build()
+        try:
+            handle = C.CDLL(str(_SO))
+        except OSError as e:  # pragma: no cover - environment specific
+            raise PulseError(f"cannot load {_SO}: {e} (the HIP library is required; there is no CPU fallback)") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.pulse_version() != 1:
+            raise PulseError("libpulse_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().pulse_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise PulseError(f"{what}: {msg} (code {rc})")
+
+
+def current_stream(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,664 @@
+// poker.hip -- hand-written gfx950 kernels for the batched no-limit hold'em step.
+//
+// Replaces the ~1,700 eager torch dispatches of one PokerGPU.step
+// (environments/Poker/PokerGPU.py:527-633) by ONE launch.
+//
+// Mapping: 16 lanes per table (one lane per seat, P <= 16), 4 tables per 64-wide wavefront,
+// 16 tables per 256-thread workgroup.  Per-table scalars are held replicated in the 16 lanes of
+// the table's DPP row; per-seat rows ([N,P] int32, exactly the reference's layout) are one
+// coalesced dword per lane.  Counting seats, "first ACTIVE seat after x" and winner selection are
+// wavefront ballots + bit tricks on the table's 16-bit slice; actor values move with ds_bpermute;
+// side-pot layers use 16-lane min/max butterflies.  All integer arithmetic is the reference's,
+// the fp32 reward keeps torch's op order (no contraction; tanh rounded once from double).
+//
+// Memory: state is read once and written once per step in the reference's own SoA tensors, so
+// the drop-in class can expose them unchanged.  The 130 MB hand-rank table is only touched by
+// tables that need an evaluation (dirty equity or showdown); its top levels live in L2, the rest
+// in the 256 MB Infinity Cache.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "pulse_internal.h"
+
+namespace {
+
+constexpr int kLanes = 16;    // lanes per table
+constexpr int kBlock = 256;   // 4 wavefronts, 16 tables
+
+// ---------------------------------------------------------------- 16-lane group primitives
+__device__ __forceinline__ uint32_t grp_ballot(bool p) {
+    const unsigned long long b = __ballot(p);
+    return (uint32_t)(b >> (threadIdx.x & 48)) & 0xFFFFu;
+}
+__device__ __forceinline__ int grp_bcast(int v, int src) { return __shfl(v, src & 15, kLanes); }
+__device__ __forceinline__ float grp_bcastf(float v, int src) { return __shfl(v, src & 15, kLanes); }
+__device__ __forceinline__ int grp_min(int v) {
+    v = min(v, __shfl_xor(v, 1, kLanes)); v = min(v, __shfl_xor(v, 2, kLanes));
+    v = min(v, __shfl_xor(v, 4, kLanes)); v = min(v, __shfl_xor(v, 8, kLanes));
+    return v;
+}
+__device__ __forceinline__ int grp_max(int v) {
+    v = max(v, __shfl_xor(v, 1, kLanes)); v = max(v, __shfl_xor(v, 2, kLanes));
+    v = max(v, __shfl_xor(v, 4, kLanes)); v = max(v, __shfl_xor(v, 8, kLanes));
+    return v;
+}
+__device__ __forceinline__ int pymod(int x, int m) { int r = x % m; return r < 0 ? r + m : r; }
+
+// first seat (x+1 .. x+A) % A whose bit is set in `bits` (bits limited to seats < A); -1 if none.
+__device__ __forceinline__ int first_after(uint32_t bits, int x, int A) {
+    const int xm = pymod(x, A);
+    const uint32_t maskA = (1u << A) - 1u;
+    const uint32_t rot = ((bits >> (xm + 1)) | (bits << (A - 1 - xm))) & maskA;   // bit k <-> seat (xm+1+k)%A
+    if (!rot) return -1;
+    int seat = xm + 1 + (__ffs((int)rot) - 1);
+    return seat >= A ? seat - A : seat;
+}
+
+// ---------------------------------------------------------------- hand-rank walk
+__device__ __forceinline__ int hr_at(const int32_t* __restrict__ hr, uint32_t len, int i) {
+    return (uint32_t)i < len ? hr[(uint32_t)i] : 0;
+}
+// seven dependent gathers: p = HR[p + c_i], p0 = 53 (PokerGPU.py:437-444).  A card of 0 re-reads
+// slot 0 of the state, which is exactly the extra HR[p] / HR[HR[p]] lookups of the turn / flop
+// equities (PokerGPU.py:500, :521), so all three streets share one 7-step chain.
+__device__ __forceinline__ int walk7(const int32_t* __restrict__ hr, uint32_t len, int c0, int c1, int c2, int c3,
+                                     int c4, int c5, int c6) {
+    int p = 53;
+    p = hr_at(hr, len, p + c0); p = hr_at(hr, len, p + c1); p = hr_at(hr, len, p + c2);
+    p = hr_at(hr, len, p + c3); p = hr_at(hr, len, p + c4); p = hr_at(hr, len, p + c5);
+    p = hr_at(hr, len, p + c6);
+    return p;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset) {
+    uint32_t c0 = (uint32_t)offset, c1 = (uint32_t)(offset >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ int rand_below(uint32_t r, int n) { return (int)__umulhi(r, (uint32_t)n); }
+__device__ __forceinline__ float rand_unit(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// ---------------------------------------------------------------- scripted opponents
+// environments/Poker/Player.py:79-176 + utils.py:121; c1,c2 = hole cards 1..52, pot = obs col 9.
+__device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot, const U4& rnd) {
+    const int r1 = pymod(c1, 13), r2 = pymod(c2, 13);
+    const int d = r1 > r2 ? r1 - r2 : r2 - r1;
+    const bool pair = r1 == r2;
+    int a = 0;
+    switch (type) {
+    case PULSE_AGENT_RANDOM:                                              // utils.py:121
+        a = rand_below(rnd.x, 13); break;
+    case PULSE_AGENT_HEURISTIC_HANDS: {                                   // Player.py:85-102
+        const bool fold = r1 < 8 && r2 < 8;
+        const bool raise = (pair || r1 >= 10 || r2 >= 10) && !fold;
+        a = raise ? 2 + rand_below(rnd.x, 9) : 0; break; }
+    case PULSE_AGENT_TIGHT_AGGRESSIVE: {                                  // Player.py:112-124
+        const bool fold = r1 < 7 && r2 < 7 && d > 5;
+        const bool raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
+        a = fold ? 0 : 1;
+        if (raise) a = 2 + 5 + rand_below(rnd.x, 4);
+        break; }
+    case PULSE_AGENT_LOOSE_PASSIVE: {                                     // Player.py:134-149
+        const bool fold = r1 <= 4 && r2 <= 4 && d > 9;
+        const bool call = ((pair && r1 > 8) || (r1 >= 11 && r2 > 9) || (r2 >= 11 && r1 > 9)) && !fold;
+        const bool raise = rand_unit(rnd.y) > 0.9f && call;
+        a = call ? 1 : 0;
+        if (raise) a = 2 + rand_below(rnd.x, 4);
+        break; }
+    case PULSE_AGENT_SMALL_BALL: {                                        // Player.py:159-174
+        const bool fold = (r1 < 6 && r2 < 6 && pot > 30) || (r1 < 9 && r2 < 9 && pot > 80);
+        const bool raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
+        a = raise ? 2 + rand_below(rnd.x, 3) : 0; break; }
+    default: break;
+    }
+    return a;
+}
+
+// ---------------------------------------------------------------- the fused step
+struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
+
+template <uint32_t PH, bool POLICY>
+__global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
+                                                           const int32_t* __restrict__ actor_idx_in,
+                                                           float* __restrict__ rewards, const PolicyArgs pa) {
+    const int gt = blockIdx.x * kBlock + threadIdx.x;
+    const int t = gt >> 4;
+    const int s = gt & 15;
+    if (t >= v.n_games) return;   // whole 16-lane groups leave together
+    const int P = v.n_players, A = v.active_players;
+    const bool seat = s < P, inA = s < A;
+    const int32_t* __restrict__ hr = v.hand_ranks;
+    const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
+    const size_t row = (size_t)t * P + s;
+
+    // ---- load (every load is independent: all in flight at once)
+    int idx = v.idx[t], button = v.button[t], pot = v.pots[t], stage = v.stages[t], dpos = v.deck_positions[t];
+    int highest = v.highest[t], agg = v.agg[t], acted = v.acted[t], lrs = v.last_raise_size[t];
+    bool done = v.is_done[t] != 0;
+    bool dirty = v.equity_dirty[t] != 0;
+    int b0 = v.board[t * 5 + 0], b1 = v.board[t * 5 + 1], b2 = v.board[t * 5 + 2], b3 = v.board[t * 5 + 3], b4 = v.board[t * 5 + 4];
+    int stack = seat ? v.stacks[row] : 0, bet = seat ? v.current_round_bet[row] : 0;
+    int inv = seat ? v.total_invested[row] : 0, status = seat ? v.status[row] : PULSE_SITOUT;
+    int h0 = -1, h1 = -1;
+    if (seat) { const int2 h = *reinterpret_cast<const int2*>(v.hands + row * 2); h0 = h.x; h1 = h.y; }
+    float eq = inA ? v.equities[(size_t)t * A + s] : 0.5f;
+    long long act64 = 0;
+    if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = actions[t];
+    const float w1 = *v.w1, w2 = *v.w2;
+    const int Kdiv = *v.K, alpha = *v.alpha;
+
+    // ---- capture (PokerGPU.py:530-539)
+    const bool prev_done = done;
+    const int actor = (PH & PULSE_PH_CAPTURE) || !actor_idx_in ? idx : actor_idx_in[t];
+    int a_status = grp_bcast(status, actor), a_stack = grp_bcast(stack, actor), a_bet = grp_bcast(bet, actor);
+    const bool has_legal_actor = a_status != PULSE_FOLDED && a_status != PULSE_ALLIN && a_status != PULSE_SITOUT && !prev_done;
+    int prev_invested = a_bet;
+    if (!(PH & PULSE_PH_CAPTURE)) prev_invested = v.prev_invested[t];
+    const int prev_stack = a_stack;
+
+    // ---- scripted opponents (environments/Poker/utils.py:108-123), fused in front of the step
+    if (POLICY) {
+        const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
+        if (type != PULSE_AGENT_EXTERNAL) {
+            const U4 rnd = philox4x32(pa.seed, pa.table_id0 + (uint64_t)t, pa.step_counter);
+            act64 = scripted_action(type, grp_bcast(h0, idx), grp_bcast(h1, idx), pot, rnd);
+            if (s == 0) actions[t] = act64;
+        }
+    }
+    const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
+
+    // ---- 1) equities of dirty tables (PokerGPU.py:455-525)
+    if (PH & PULSE_PH_EQUITY) {
+        if (dirty) {
+            float e = 0.5f;
+            if (inA && stage >= 1 && stage <= 3) {
+                const int c5 = stage >= 2 ? b3 : 0, c6 = stage == 3 ? b4 : 0;
+                const float r = (float)walk7(hr, hr_len, h0, h1, b0, b1, b2, c5, c6);
+                e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
+                e = fminf(fmaxf(e, 0.0f), 1.0f);
+            }
+            eq = e;
+            if (inA) v.equities[(size_t)t * A + s] = e;
+            dirty = false;
+        }
+    }
+    const float e_actor = grp_bcastf(eq, actor);
+
+    // ---- 2) execute the action of the seat to act (PokerGPU.py:230-303)
+    if (PH & PULSE_PH_EXECUTE) {
+        const int call_cost = highest - a_bet;
+        const bool active = a_status != PULSE_FOLDED && a_status != PULSE_ALLIN && a_status != PULSE_SITOUT && !done;
+        if (active && action >= 0) {
+            int n_stack = a_stack, n_bet = a_bet, n_inv_add = 0, n_status = a_status;
+            if (action == 0) {
+                n_status = PULSE_FOLDED;
+            } else {
+                int raise_amt = 0;
+                if (action == 2) raise_amt = lrs;
+                else if (action == 12) raise_amt = a_stack;
+                else if (action >= 3 && action <= 11) {
+                    const float fr = action == 3 ? 0.25f : action == 4 ? 0.33f : action == 5 ? 0.50f : action == 6 ? 0.75f
+                                   : action == 7 ? 1.00f : action == 8 ? 1.50f : action == 9 ? 2.00f : action == 10 ? 3.00f : 4.00f;
+                    raise_amt = (int)__fmul_rn((float)pot, fr);
+                }
+                const int total = action == 1 ? call_cost : call_cost + raise_amt;
+                const int amt = min(total, a_stack);
+                const bool is_raise = action >= 2 && amt > call_cost;
+                n_stack = a_stack - amt; n_bet = a_bet + amt; n_inv_add = amt; pot += amt;
+                if (n_stack == 0) n_status = PULSE_ALLIN;
+                if (is_raise) {
+                    const int raise_size = n_bet - highest;
+                    highest = n_bet;
+                    if (raise_size >= lrs) { agg = idx; acted = 0; lrs = raise_size; }
+                }
+            }
+            acted += 1;
+            if (s == (idx & 15)) { stack = n_stack; bet = n_bet; inv += n_inv_add; status = n_status; }
+        }
+    }
+
+    const uint32_t act_bits = grp_ballot(status == PULSE_ACTIVE);
+    const uint32_t cont_bits = grp_ballot(status == PULSE_ACTIVE || status == PULSE_ALLIN);
+    const int contenders = __popc(cont_bits);
+
+    // ---- 3) next actor, round close, street transition (PokerGPU.py:547-616)
+    if (PH & PULSE_PH_ADVANCE) {
+        const int truly_active = __popc(act_bits);
+        const bool all_acted = acted >= truly_active;
+        bool round_over = done || truly_active == 0;
+        const uint32_t maskA = (1u << A) - 1u;
+        const int next_seat = first_after(act_bits & maskA, idx, A);
+        const bool has_next = next_seat >= 0;
+        const bool closes = all_acted && (idx == agg || (has_next && next_seat == agg));
+        round_over = round_over || !has_next || closes;
+        if (!round_over && has_next) idx = next_seat;
+        const bool early_term = contenders <= 1 && round_over;
+        if (early_term) done = true;
+        if (round_over && !early_term && !done) {
+            lrs = 1; stage += 1; highest = 0; agg = pymod(button + 1, A); acted = 0; bet = 0;
+            const int first = first_after(act_bits & maskA, button, A);
+            if (first >= 0) idx = first;
+            if (stage > 3) { done = true; stage = 4; }
+            else {
+                const int32_t* dk = v.decks + (size_t)t * 52;
+                if (stage == 1) {
+                    b0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
+                    b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                    dpos += 4;
+                } else if (stage == 2) { b3 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0; dpos += 2; }
+                else { b4 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0; dpos += 2; }
+                dirty = true;
+            }
+        }
+    }
+
+    // ---- 4) payouts on newly finished tables (PokerGPU.py:619-623)
+    const bool newly_done = (PH & PULSE_PH_CAPTURE) ? (done && !prev_done) : done;
+    if (PH & PULSE_PH_FOLDWIN) {                                            // :331-338
+        if (newly_done && contenders == 1) {
+            if (s == __ffs((int)cont_bits) - 1) stack += pot;
+            pot = 0;
+        }
+    }
+    if (PH & PULSE_PH_SHOWDOWN) {                                           // :380-453
+        if (newly_done && stage < 5 && contenders > 1) {
+            const int32_t* dk = v.decks + (size_t)t * 52;
+            if (stage == 0) {
+                b0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
+                b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                b3 = (uint32_t)(dpos + 5) < 52u ? dk[dpos + 5] : 0;
+                b4 = (uint32_t)(dpos + 7) < 52u ? dk[dpos + 7] : 0;
+                dpos += 8;
+            } else if (stage == 1) {
+                b3 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                b4 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                dpos += 4;
+            } else if (stage == 2) {
+                b4 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                dpos += 2;
+            }
+            const bool eligible = inA && (status == PULSE_ACTIVE || status == PULSE_ALLIN);
+            int rank = INT_MIN;
+            if (eligible) rank = walk7(hr, hr_len, h0, h1, b0, b1, b2, b3, b4);
+            // side pots, one layer per distinct commitment level (PokerGPU.py:340-378)
+            int payout = 0, prev_level = 0;
+            for (int l = 0; l < A; ++l) {
+                const int level = grp_min(inA && inv > prev_level ? inv : INT_MAX);
+                if (level == INT_MAX) break;
+                const bool contrib = inA && inv >= level;
+                const int n_contrib = __popc(grp_ballot(contrib));
+                const int best = grp_max(contrib && eligible ? rank : INT_MIN);
+                const bool win = contrib && eligible && rank == best;
+                const uint32_t win_bits = grp_ballot(win);
+                const int n_win = __popc(win_bits);
+                if (n_win > 0) {
+                    const int layer_pot = (level - prev_level) * n_contrib;
+                    const int share = layer_pot / n_win, rem = layer_pot - share * n_win;
+                    if (win) payout += share + (s == __ffs((int)win_bits) - 1 ? rem : 0);
+                }
+                prev_level = level;
+            }
+            stack += payout;
+            pot = 0; stage = 5;
+        }
+    }
+    if (PH & PULSE_PH_CLEARDONE) {                                          // :625-628
+        if (done) { bet = 0; inv = 0; highest = 0; }
+    }
+
+    // ---- 5) shaped reward (PokerGPU.py:305-329, :631-632)
+    if (PH & PULSE_PH_REWARD) {
+        const float cnt = (float)contenders;
+        const float fair = __fdiv_rn(1.0f, fmaxf(cnt, 1.0f));
+        const int cc = max(0, highest - prev_invested);
+        const float potf = (float)pot;
+        const float m = __fmul_rn(e_actor, potf);
+        const float o = __fdiv_rn((float)cc, __fadd_rn((float)(pot + cc), 1e-6f));
+        float sv = 0.0f;
+        if (action == 1) sv = __fmul_rn(__fsub_rn(e_actor, o), potf);
+        else if (action == 0) sv = __fmul_rn(__fsub_rn(o, e_actor), potf);
+        else if (action >= 2) sv = __fmul_rn(__fsub_rn(e_actor, fair), potf);
+        const float x = __fdiv_rn(__fadd_rn(__fmul_rn(w1, m), __fmul_rn(w2, sv)), (float)Kdiv);
+        float r = __fmul_rn((float)alpha, (float)tanh((double)x));
+        if ((PH & PULSE_PH_CAPTURE) && (!has_legal_actor || prev_done)) r = 0.0f;
+        if (s == 0) rewards[t] = r;
+    }
+
+    // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
+    if (PH & PULSE_PH_OBS) {
+        float* __restrict__ o = v.obs + (size_t)t * v.obs_size;
+        const int n_h0 = grp_bcast(h0, idx), n_h1 = grp_bcast(h1, idx);
+        const int n_stack = grp_bcast(stack, idx), n_status = grp_bcast(status, idx), n_bet = grp_bcast(bet, idx);
+        if (s < 13) {
+            int hv;
+            switch (s) {
+            case 0: hv = b0; break; case 1: hv = b1; break; case 2: hv = b2; break; case 3: hv = b3; break;
+            case 4: hv = b4; break; case 5: hv = n_h0; break; case 6: hv = n_h1; break; case 7: hv = stage; break;
+            case 8: hv = pymod(idx - button, A); break; case 9: hv = pot; break; case 10: hv = highest - n_bet; break;
+            case 11: hv = n_stack; break; default: hv = n_status; break;
+            }
+            o[s] = (float)hv;
+        }
+        // opponents: seat (idx+1+k)%A -> columns 13+3k..; lanes >= A zero-fill the padding slots
+        const int idxm = pymod(idx, A);
+        if (s < v.max_players && s != idxm) {
+            int k; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+            if (inA) { k = s - idxm - 1; if (k < 0) k += A; f0 = (float)stack; f1 = (float)status; f2 = (float)bet; }
+            else k = s - 1;
+            float* dst = o + 13 + 3 * k;
+            dst[0] = f0; dst[1] = f1; dst[2] = f2;
+        }
+    }
+
+    // ---- store
+    if (seat) {
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.stacks[row] = stack;
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.current_round_bet[row] = bet;
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) v.total_invested[row] = inv;
+        if (PH & PULSE_PH_EXECUTE) v.status[row] = status;
+    }
+    if ((PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) && s < 5) {
+        const int bv = s == 0 ? b0 : s == 1 ? b1 : s == 2 ? b2 : s == 3 ? b3 : b4;
+        v.board[t * 5 + s] = bv;
+    }
+    if (s == 0) {
+        if (PH & PULSE_PH_CAPTURE) { v.prev_stacks[t] = prev_stack; v.prev_invested[t] = prev_invested; }
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.pots[t] = pot;
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.highest[t] = highest;
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { v.agg[t] = agg; v.acted[t] = acted; v.last_raise_size[t] = lrs; }
+        if (PH & PULSE_PH_ADVANCE) v.idx[t] = idx;
+        if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { v.stages[t] = stage; v.deck_positions[t] = dpos; }
+        if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) v.equity_dirty[t] = dirty ? 1 : 0;
+        if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------- standalone policy (build_actions)
+__global__ __launch_bounds__(kBlock) void poker_policy_kernel(const float* __restrict__ obs, int obs_stride,
+                                                             const int32_t* __restrict__ seat_idx, int n,
+                                                             PolicyArgs pa, int64_t* __restrict__ actions) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    const int seat = seat_idx[t];
+    const int type = (int)((pa.types_packed >> (4 * (seat & 15))) & 15u);
+    if (type == PULSE_AGENT_EXTERNAL) return;
+    const float* o = obs + (size_t)t * obs_stride;
+    const U4 rnd = philox4x32(pa.seed, pa.table_id0 + (uint64_t)t, pa.step_counter);
+    actions[t] = scripted_action(type, (int)o[5], (int)o[6], (int)o[9], rnd);
+}
+
+// ---------------------------------------------------------------- standalone evaluator (tests / micro-bench)
+__global__ __launch_bounds__(kBlock) void poker_eval_kernel(const int32_t* __restrict__ hr, uint32_t len,
+                                                           const int32_t* __restrict__ cards, int n_hands, int n_cards,
+                                                           int flop_double, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_hands) return;
+    const int32_t* c = cards + (size_t)i * n_cards;
+    const int c5 = n_cards > 5 ? c[5] : 0, c6 = n_cards > 6 ? c[6] : 0;
+    int p;
+    if (n_cards == 5 && !flop_double) {
+        p = 53;
+        for (int k = 0; k < 5; ++k) p = hr_at(hr, len, p + c[k]);
+        p = hr_at(hr, len, p);
+    } else {
+        p = walk7(hr, len, c[0], c[1], c[2], c[3], c[4], c5, c6);
+    }
+    out[i] = p;
+}
+
+// ---------------------------------------------------------------- reset (PokerGPU.py:73-157)
+template <bool SHUFFLE>
+__global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerView v, const PulsePokerResetOpts o) {
+    __shared__ uint32_t keys[kBlock / kLanes][52];
+    __shared__ int32_t deck_s[kBlock / kLanes][52];
+    const int gt = blockIdx.x * kBlock + threadIdx.x;
+    const int t = gt >> 4, s = gt & 15, g = threadIdx.x >> 4;
+    if (t >= v.n_games) return;
+    const int P = v.n_players, A = v.active_players;
+    const bool seat = s < P, inA = s < A;
+    const size_t row = (size_t)t * P + s;
+    int32_t* dk = o.decks_out + (size_t)t * 52;
+
+    // decks: prefixed copy (:88-92) or rank-of-random-key shuffle == rand().argsort()+1 (:86).
+    // The table's 16 lanes sit in one wavefront, LDS ops of a wavefront retire in order, so the
+    // wavefront-scope fences below are all the synchronisation the staging needs.
+    if (SHUFFLE) {
+        if (s < 13) {
+            const U4 r = philox4x32(o.seed, o.table_id0 + (uint64_t)t, o.episode * 16 + (uint64_t)s);
+            keys[g][4 * s + 0] = r.x; keys[g][4 * s + 1] = r.y; keys[g][4 * s + 2] = r.z; keys[g][4 * s + 3] = r.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // card c (0..51) lands at position #{keys < key[c]} (ties by index): deck[pos] = c + 1
+        if (s < 13) {
+            for (int q = 0; q < 4; ++q) {
+                const int c = 4 * s + q;
+                const uint32_t kc = keys[g][c];
+                int pos = 0;
+                for (int j = 0; j < 52; ++j) { const uint32_t kj = keys[g][j]; pos += (kj < kc) || (kj == kc && j < c); }
+                deck_s[g][pos] = c + 1;
+            }
+        }
+    } else {
+        const int32_t* src = o.prefixed_decks + (size_t)t * 52;
+        for (int c = s; c < 52; c += kLanes) deck_s[g][c] = src[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int c = s; c < 52; c += kLanes) dk[c] = deck_s[g][c];
+
+    // stacks: refill busted / over-max, then torch.roll by `rotation` (:101-110)
+    int st = o.starting_bbs;
+    if (seat && !o.first) {
+        const int src = pymod(s - o.rotation, P);
+        st = v.stacks[(size_t)t * P + src];
+        if (st == 0 || st > o.max_bbs) st = o.starting_bbs;
+    }
+    // the store of this seat's stack below depends on the load above, and a wavefront's load
+    // instruction has returned for all its lanes by then: no lane overwrites a seat unread.
+    int h0 = -1, h1 = -1;
+    if (inA) { h0 = deck_s[g][2 * s]; h1 = deck_s[g][2 * s + 1]; }                     // :112-114
+    const int button = o.first ? 0 : pymod(v.button[t] + 1, A);                         // :121
+    int sb, bb, idx;
+    if (A == 2) { sb = button; bb = pymod(button + 1, A); idx = button; }               // :123-125,:131
+    else { sb = pymod(button + 1, A); bb = pymod(button + 2, A); idx = pymod(bb + 1, A); }
+    int bet = 0, inv = 0, status = inA ? PULSE_ACTIVE : PULSE_SITOUT;
+    if (s == bb) { st -= 1; bet = 1; inv = 1; status = st == 0 ? PULSE_ALLIN : PULSE_ACTIVE; }   // :188-199
+    if (seat) {
+        v.stacks[row] = st; v.current_round_bet[row] = bet; v.total_invested[row] = inv; v.status[row] = status;
+        *reinterpret_cast<int2*>(v.hands + row * 2) = make_int2(h0, h1);
+    }
+    if (inA) v.equities[(size_t)t * A + s] = 0.5f;                                      // :144
+    if (s < 5) v.board[t * 5 + s] = -1;                                                 // :95
+    if (s == 0) {
+        v.last_raise_size[t] = 1; v.deck_positions[t] = 2 * A; v.pots[t] = 1; v.stages[t] = 0;
+        v.button[t] = button; v.sb[t] = sb; v.bb[t] = bb; v.idx[t] = idx;
+        v.highest[t] = 1; v.agg[t] = bb; v.acted[t] = 0; v.is_done[t] = 0; v.is_done_out[t] = 0;
+        v.equity_dirty[t] = 1; v.prev_stacks[t] = 0; v.prev_invested[t] = 0;
+    }
+    // first observation (:157 -> :159-179)
+    float* __restrict__ ob = v.obs + (size_t)t * v.obs_size;
+    const int a_h0 = grp_bcast(h0, idx), a_h1 = grp_bcast(h1, idx);
+    const int a_stack = grp_bcast(st, idx), a_status = grp_bcast(status, idx), a_bet = grp_bcast(bet, idx);
+    if (s < 13) {
+        int hv;
+        switch (s) {
+        case 0: case 1: case 2: case 3: case 4: hv = -1; break;
+        case 5: hv = a_h0; break; case 6: hv = a_h1; break; case 7: hv = 0; break;
+        case 8: hv = pymod(idx - button, A); break; case 9: hv = 1; break; case 10: hv = 1 - a_bet; break;
+        case 11: hv = a_stack; break; default: hv = a_status; break;
+        }
+        ob[s] = (float)hv;
+    }
+    if (s < v.max_players && s != idx) {
+        int k; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+        if (inA) { k = s - idx - 1; if (k < 0) k += A; f0 = (float)st; f1 = (float)status; f2 = (float)bet; }
+        else k = s - 1;
+        float* dst = ob + 13 + 3 * k;
+        dst[0] = f0; dst[1] = f1; dst[2] = f2;
+    }
+}
+
+// ---------------------------------------------------------------- episode statistics
+__global__ __launch_bounds__(kBlock) void poker_stats_kernel(const uint8_t* __restrict__ is_done,
+                                                            const float* __restrict__ rewards,
+                                                            const uint8_t* __restrict__ mask, int n,
+                                                            unsigned long long* stats, double* fstats) {
+    int cnt = 0; double sum = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        cnt += is_done ? (is_done[i] != 0) : 0;
+        if (rewards && (!mask || mask[i])) sum += (double)rewards[i];
+    }
+    for (int m = 32; m >= 1; m >>= 1) { cnt += __shfl_xor(cnt, m); sum += __shfl_xor(sum, m); }
+    __shared__ int scnt[kBlock / 64]; __shared__ double ssum[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { scnt[threadIdx.x >> 6] = cnt; ssum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0; double sm = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) { c += scnt[w]; sm += ssum[w]; }
+        if (c) atomicAdd(stats, (unsigned long long)c);
+        if (rewards && sm != 0.0) atomicAdd(fstats, sm);
+    }
+}
+
+// ---------------------------------------------------------------- host side
+int check_view(const PulsePokerView* v, const char* who) {
+    if (!v) return pulse::fail(PULSE_EINVAL, "null PulsePokerView");
+    if (v->n_games < 0 || v->n_players < 2 || v->n_players > PULSE_MAX_SEATS || v->max_players > PULSE_MAX_SEATS ||
+        v->max_players < v->n_players || v->active_players < 2 || v->active_players > v->n_players ||
+        v->obs_size != 13 + 3 * (v->max_players - 1))
+        return pulse::fail(PULSE_EINVAL, "PulsePokerView: unsupported shape (need 2 <= active <= n_players <= max_players <= 16, obs_size = 13+3*(max_players-1))");
+    const void* ptrs[] = {v->hand_ranks, v->pots, v->stages, v->deck_positions, v->button, v->sb, v->bb, v->idx, v->highest,
+                          v->agg, v->acted, v->last_raise_size, v->prev_stacks, v->prev_invested, v->is_done, v->is_done_out,
+                          v->equity_dirty, v->stacks, v->current_round_bet, v->total_invested, v->status, v->hands, v->board,
+                          v->decks, v->equities, v->obs, v->w1, v->w2, v->K, v->alpha};
+    for (const void* p : ptrs)
+        if (!p) return pulse::fail(PULSE_EINVAL, "PulsePokerView: null device pointer");
+    if (v->hand_ranks_len <= 53) return pulse::fail(PULSE_EINVAL, "PulsePokerView: hand_ranks_len too small");
+    (void)who;
+    return 0;
+}
+
+inline int grid_for_tables(int n) { return (int)(((long long)n * kLanes + kBlock - 1) / kBlock); }
+
+int finish_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pulse::fail_hip((int)e, what);
+    return 0;
+}
+
+uint64_t pack_types(const uint8_t* agent_types, int n_players) {
+    uint64_t packed = 0;
+    for (int i = 0; i < n_players && i < 16; ++i) packed |= (uint64_t)(agent_types[i] & 15u) << (4 * i);
+    return packed;
+}
+
+template <uint32_t PH>
+void launch_phase(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, hipStream_t st) {
+    hipLaunchKernelGGL((poker_step_kernel<PH, false>), dim3(grid_for_tables(v.n_games)), dim3(kBlock), 0, st, v, actions,
+                       actor_idx, rewards, PolicyArgs{0, 0, 0, 0});
+}
+
+}  // namespace
+
+extern "C" {
+
+int pulse_poker_step(const PulsePokerView* v, const int64_t* actions, float* rewards, void* stream) {
+    if (int rc = check_view(v, "pulse_poker_step")) return rc;
+    if (!actions || !rewards) return pulse::fail(PULSE_EINVAL, "pulse_poker_step: null actions/rewards");
+    if (v->n_games == 0) return 0;
+    launch_phase<PULSE_PH_STEP>(*v, const_cast<int64_t*>(actions), nullptr, rewards, (hipStream_t)stream);
+    return finish_launch("pulse_poker_step");
+}
+
+int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
+                            uint64_t table_id0, int64_t* actions, float* rewards, void* stream) {
+    if (int rc = check_view(v, "pulse_poker_policy_step")) return rc;
+    if (!actions || !rewards || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_policy_step: null argument");
+    if (v->n_games == 0) return 0;
+    const PolicyArgs pa{pack_types(agent_types, v->n_players), seed, step_counter, table_id0};
+    hipLaunchKernelGGL((poker_step_kernel<PULSE_PH_STEP, true>), dim3(grid_for_tables(v->n_games)), dim3(kBlock), 0,
+                       (hipStream_t)stream, *v, actions, (const int32_t*)nullptr, rewards, pa);
+    return finish_launch("pulse_poker_policy_step");
+}
+
+int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* actions, const int32_t* actor_idx,
+                       float* rewards, void* stream) {
+    if (int rc = check_view(v, "pulse_poker_phases")) return rc;
+    if ((phases & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && !actions)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_phases: actions required for EXECUTE/REWARD");
+    if ((phases & PULSE_PH_REWARD) && !rewards) return pulse::fail(PULSE_EINVAL, "pulse_poker_phases: rewards required for REWARD");
+    if (v->n_games == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t* a = const_cast<int64_t*>(actions);
+    switch (phases) {
+    case PULSE_PH_STEP: launch_phase<PULSE_PH_STEP>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_STEP & ~PULSE_PH_EQUITY: launch_phase<(PULSE_PH_STEP & ~PULSE_PH_EQUITY)>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_EQUITY: launch_phase<PULSE_PH_EQUITY>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_EXECUTE: launch_phase<PULSE_PH_EXECUTE>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_ADVANCE: launch_phase<PULSE_PH_ADVANCE>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_FOLDWIN: launch_phase<PULSE_PH_FOLDWIN>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_SHOWDOWN: launch_phase<PULSE_PH_SHOWDOWN>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN: launch_phase<(PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_CLEARDONE: launch_phase<PULSE_PH_CLEARDONE>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_REWARD: launch_phase<PULSE_PH_REWARD>(*v, a, actor_idx, rewards, st); break;
+    case PULSE_PH_OBS: launch_phase<PULSE_PH_OBS>(*v, a, nullptr, rewards, st); break;
+    default: return pulse::fail(PULSE_EINVAL, "pulse_poker_phases: unsupported phase combination");
+    }
+    return finish_launch("pulse_poker_phases");
+}
+
+int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream) {
+    if (int rc = check_view(v, "pulse_poker_reset")) return rc;
+    if (!o || !o->decks_out) return pulse::fail(PULSE_EINVAL, "pulse_poker_reset: null options / decks_out");
+    if (v->n_games == 0) return 0;
+    const dim3 grid(grid_for_tables(v->n_games)), block(kBlock);
+    if (o->prefixed_decks) hipLaunchKernelGGL((poker_reset_kernel<false>), grid, block, 0, (hipStream_t)stream, *v, *o);
+    else hipLaunchKernelGGL((poker_reset_kernel<true>), grid, block, 0, (hipStream_t)stream, *v, *o);
+    return finish_launch("pulse_poker_reset");
+}
+
+int pulse_poker_policy(const float* obs, int32_t obs_stride, const int32_t* seat_idx, int32_t n, const uint8_t* agent_types,
+                       int32_t n_players, uint64_t seed, uint64_t step_counter, uint64_t table_id0, int64_t* actions,
+                       void* stream) {
+    if (!obs || !seat_idx || !agent_types || !actions || n < 0 || obs_stride < 10 || n_players < 1 || n_players > 16)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_policy: bad argument");
+    if (n == 0) return 0;
+    const PolicyArgs pa{pack_types(agent_types, n_players), seed, step_counter, table_id0};
+    hipLaunchKernelGGL(poker_policy_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, obs,
+                       obs_stride, seat_idx, n, pa, actions);
+    return finish_launch("pulse_poker_policy");
+}
+
+int pulse_poker_eval_hands(const int32_t* hand_ranks, int32_t hand_ranks_len, const int32_t* cards, int32_t n_hands,
+                           int32_t n_cards, int32_t flop_double, int32_t* out, void* stream) {
+    if (!hand_ranks || !cards || !out || n_hands < 0 || n_cards < 5 || n_cards > 7 || hand_ranks_len <= 53)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_eval_hands: bad argument");
+    if (n_hands == 0) return 0;
+    hipLaunchKernelGGL(poker_eval_kernel, dim3((n_hands + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       hand_ranks, (uint32_t)hand_ranks_len, cards, n_hands, n_cards, flop_double, out);
+    return finish_launch("pulse_poker_eval_hands");
+}
+
+int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n, int64_t* stats,
+                      double* fstats, void* stream) {
+    if (!stats || (rewards && !fstats) || n < 0) return pulse::fail(PULSE_EINVAL, "pulse_poker_stats: bad argument");
+    if (n == 0) return 0;
+    const int grid = min(1024, (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(poker_stats_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, is_done, rewards, mask, n,
+                       reinterpret_cast<unsigned long long*>(stats), fstats);
+    return finish_launch("pulse_poker_stats");
+}
+
+}  // extern "C"

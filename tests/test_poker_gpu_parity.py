@@ -1,0 +1,185 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via the drop-in PokerGPU class) against
+  (1) golden fixtures recorded from the reference itself (tests/golden/make_golden.py), and
+  (2) the oracle (oracle/poker_oracle.c) on seeded inputs at BASELINE.json's config-2 size.
+Integer state, observations, equities and dones are compared bit-exact; fp32 rewards within
+tests.helpers.reward_tol (documented there)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import DYN_BOOL, DYN_I32, DYN_ROWS, INT_KEYS, assert_state_equal, reward_tol, to_np
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _gpu_env(**kw):
+    from pulselib_amd.environments.Poker import PokerGPU
+    return PokerGPU(device=torch.device(DEV), agents=[], **kw)
+
+
+def _snap(env):
+    d = {n: to_np(getattr(env, n)) for n in INT_KEYS}
+    d["equities"] = to_np(env.equities)
+    d["obs"] = to_np(env.obs)
+    return d
+
+
+def _force_A(A):
+    class _Ctx:
+        def __enter__(self):
+            self.orig = torch.randint
+            torch.randint = lambda low, high, size, device=None: torch.tensor([A])
+        def __exit__(self, *a):
+            torch.randint = self.orig
+    return _Ctx()
+
+
+@pytest.fixture(scope="module")
+def rollouts(golden_dir):
+    return np.load(golden_dir / "poker_rollouts.npz")
+
+
+@pytest.fixture(scope="module")
+def methods(golden_dir):
+    return np.load(golden_dir / "poker_methods.npz")
+
+
+@pytest.mark.parametrize("case", ["p10_uniform", "p10_callish", "p10_allin", "p6_allin", "p2_headsup", "p4_wild"])
+def test_hip_matches_reference_rollout(rollouts, case):
+    P, MP, N, episodes, steps = [int(x) for x in rollouts[f"{case}/meta"]]
+    env = _gpu_env(n_players=P, max_players=MP, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
+    tol = reward_tol(50)
+    for e in range(episodes):
+        A = int(rollouts[f"{case}/A"][e])
+        decks = torch.from_numpy(rollouts[f"{case}/e{e}/decks"].astype(np.int32))
+        with _force_A(A):
+            obs, info = env.reset(options={"active_players": True, "q_agent_seat": int(rollouts[f"{case}/q_seat"][e]),
+                                           "rotation": int(rollouts[f"{case}/rotation"][e]), "prefixed_decks": decks})
+        want = {k: rollouts[f"{case}/e{e}/reset/{k}"] for k in INT_KEYS + ("equities", "obs")}
+        got = _snap(env)
+        assert_state_equal(got, want, ctx=f"{case} e{e} reset")
+        np.testing.assert_array_equal(got["obs"], want["obs"])
+        np.testing.assert_array_equal(got["equities"], want["equities"])
+        acts = rollouts[f"{case}/e{e}/actions"].astype(np.int64)
+        for s in range(steps):
+            obs, rew, dones, trunc, info = env.step(torch.from_numpy(acts[s]).to(DEV))
+            want = {k: rollouts[f"{case}/e{e}/steps/{k}"][s] for k in INT_KEYS + ("equities", "obs")}
+            ctx = f"{case} e{e} step {s}"
+            got = _snap(env)
+            assert_state_equal(got, want, ctx=ctx)
+            np.testing.assert_array_equal(to_np(obs), want["obs"], err_msg=ctx)
+            np.testing.assert_array_equal(got["equities"], want["equities"], err_msg=ctx)
+            np.testing.assert_array_equal(to_np(dones).astype(np.uint8), rollouts[f"{case}/e{e}/steps/dones"][s], err_msg=ctx)
+            np.testing.assert_allclose(to_np(rew), rollouts[f"{case}/e{e}/steps/rewards"][s], rtol=0, atol=tol, err_msg=ctx)
+            assert info["seat_idx"] is env.idx and info["stacks"] is env.stacks
+
+
+def _poked_env(methods, key):
+    P, A, N = [int(x) for x in methods[f"{key}/meta"]]
+    env = _gpu_env(n_players=P, max_players=10, n_games=N, w1=.5, w2=.3, K=100, alpha=50)
+    with _force_A(A):
+        env.reset(options={"active_players": True, "prefixed_decks": torch.from_numpy(methods[f"{key}/decks"].astype(np.int32))})
+    for k in DYN_I32 + DYN_ROWS:
+        getattr(env, k)[...] = torch.from_numpy(methods[f"{key}/pre/{k}"].astype(np.int32)).to(DEV)
+    for k in DYN_BOOL:
+        getattr(env, k)[...] = torch.from_numpy(methods[f"{key}/pre/{k}"].astype(bool)).to(DEV)
+    env.equities[...] = torch.from_numpy(methods[f"{key}/pre/equities"]).to(DEV)
+    return env
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_hip_methods_match_reference(methods, ci):
+    key = f"c{ci}"
+    env = _poked_env(methods, key)
+    np.testing.assert_array_equal(to_np(env.get_obs()), methods[f"{key}/get_obs/obs"])
+
+    env = _poked_env(methods, key)
+    env.calculate_equities()
+    np.testing.assert_array_equal(to_np(env.equities), methods[f"{key}/calculate_equities/equities"])
+    np.testing.assert_array_equal(to_np(env.equity_dirty).astype(np.uint8), methods[f"{key}/calculate_equities/equity_dirty"])
+
+    env = _poked_env(methods, key)
+    env.execute_actions(torch.from_numpy(methods[f"{key}/execute_actions/actions"]))
+    assert_state_equal(_snap(env), {k: methods[f"{key}/execute_actions/post/{k}"] for k in INT_KEYS}, ctx=f"{key} execute_actions")
+
+    env = _poked_env(methods, key)
+    env.is_done[...] = torch.from_numpy(methods[f"{key}/resolve/is_done"].astype(bool)).to(DEV)
+    env.resolve_fold_winners()
+    env.resolve_terminated_games()
+    assert_state_equal(_snap(env), {k: methods[f"{key}/resolve/post/{k}"] for k in INT_KEYS}, ctx=f"{key} resolve")
+
+    env = _poked_env(methods, key)
+    env.is_done[...] = torch.from_numpy(methods[f"{key}/step/is_done_pre"].astype(bool)).to(DEV)
+    obs, rew, dones, _, _ = env.step(torch.from_numpy(methods[f"{key}/step/actions"]))
+    got = _snap(env)
+    assert_state_equal(got, {k: methods[f"{key}/step/post/{k}"] for k in INT_KEYS}, ctx=f"{key} step")
+    np.testing.assert_array_equal(got["obs"], methods[f"{key}/step/post/obs"])
+    np.testing.assert_array_equal(got["equities"], methods[f"{key}/step/post/equities"])
+    np.testing.assert_array_equal(to_np(dones).astype(np.uint8), methods[f"{key}/step/dones"])
+    np.testing.assert_allclose(to_np(rew), methods[f"{key}/step/rewards"], rtol=0, atol=reward_tol(50))
+
+
+def _seeded_decks(n, seed):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return (torch.rand((n, 52), generator=g).argsort(dim=1) + 1).to(torch.int32)
+
+
+@pytest.mark.parametrize("N,P,As", [(65536, 10, (10, 7, 2)), (4099, 6, (6, 3)), (1, 2, (2,)), (17, 16, (16, 9))])
+def test_hip_matches_oracle_at_scale(oracle_table, N, P, As):
+    """Config-2 size (65,536 tables, 10 seats) and ragged sizes: every step compared with the oracle."""
+    from oracle import oracle as orc
+    MP = max(P, 10)
+    kw = dict(n_players=P, max_players=MP, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
+    env = _gpu_env(**kw)
+    ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
+    rng = np.random.default_rng(N + P)
+    tol = reward_tol(50)
+    steps = 40 if N > 10000 else 60
+    for e, A in enumerate(As):
+        decks = _seeded_decks(N, 20260401 + e)
+        opts = {"q_agent_seat": e % A, "rotation": e, "prefixed_decks": decks}
+        with _force_A(A):
+            env.reset(options=dict(opts, active_players=True))
+        ref.reset(options=dict(opts, active_players=A, prefixed_decks=decks.numpy()))
+        assert_state_equal(_snap(env), ref.snapshot(), ctx=f"reset e{e}")
+        np.testing.assert_array_equal(to_np(env.obs), ref.obs)
+        for s in range(steps):
+            p = [.08, .50, .08, .03, .03, .03, .03, .03, .03, .02, .02, .02, .10]
+            a = rng.choice(13, N, p=p).astype(np.int64)
+            obs, rew, dones, _, _ = env.step(torch.from_numpy(a).to(DEV))
+            robs, rrew, rdones, _, _ = ref.step(a)
+            ctx = f"N={N} e{e} step {s}"
+            got = _snap(env)
+            assert_state_equal(got, ref.snapshot(), ctx=ctx)
+            np.testing.assert_array_equal(got["obs"], robs, err_msg=ctx)
+            np.testing.assert_array_equal(got["equities"], ref.equities, err_msg=ctx)
+            np.testing.assert_array_equal(to_np(dones), rdones, err_msg=ctx)
+            np.testing.assert_allclose(to_np(rew), rrew, rtol=0, atol=tol, err_msg=ctx)
+        assert to_np(env.is_done).mean() > 0.5
+
+
+def test_eval_hands_kernel_matches_golden_vectors(golden_dir):
+    import ctypes as C
+    from pulselib_amd import _native, handranks
+    vec = np.load(golden_dir / "handranks_vectors.npz")
+    table = handranks.device_table(DEV)
+    assert table.numel() == int(vec["size"])
+    hands = torch.from_numpy(vec["hands"].astype(np.int32)).to(DEV)
+    lib = _native.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    for n_cards, dbl, key in ((7, 0, "rank7"), (6, 0, "rank6"), (5, 0, "rank5"), (5, 1, "flop_double")):
+        cards = hands[:, :n_cards].contiguous()
+        out = torch.empty(cards.shape[0], dtype=torch.int32, device=DEV)
+        _native.check(lib.pulse_poker_eval_hands(table.data_ptr(), table.numel(), cards.data_ptr(), cards.shape[0], n_cards, dbl,
+                                                 out.data_ptr(), stream))
+        np.testing.assert_array_equal(out.cpu().numpy(), vec[key], err_msg=key)
+
+
+def test_device_table_digest_matches_golden(golden_dir):
+    import hashlib
+    from pulselib_amd import handranks
+    vec = np.load(golden_dir / "handranks_vectors.npz")
+    assert hashlib.sha256(handranks.host_table().tobytes()).hexdigest() == str(vec["sha256"])
