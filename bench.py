@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the Poker batched env-step hot path on MI355X.
+
+Workload (BASELINE.json configs[1], config/pokerGPU.yaml of the reference): 65,536 parallel tables per
+GPU, 10 seats (the 9 scripted opponents of pokerGPU.yaml:5-14 + the Q seat, played by `random` in this
+env-only measurement), STARTING_BBS 100, W1 .5, W2 .3, K 100, ALPHA 50; decks shuffled on device
+(reference: rand().argsort() per reset, PokerGPU.py:86); `active_players` sampled 2..10 per episode
+(PokerGPU.py:76-80) from a host RNG seeded 0; seat rotation per episode as scripts/Poker/trainGPU.py:58-72;
+episode stop rule of trainGPU.py:27-33 (every 5th step, >80 % of tables done), evaluated without a host
+sync one 5-step chunk late (--stop-rule sync gives the reference's blocking check).
+
+One "step" = one pass of the hot path over the batch = scripted-opponent policy + PokerGPU.step, ONE fused
+HIP launch (pulse_poker_policy_step).  Steps are counted like the reference: n_tables x step calls,
+finished tables included (trainGPU.py:108).  Resets run inside the timed region and are not counted.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the fused step kernel: algorithmic bytes per launch
+(453 B per table-step) over the kernel's mean duration from HIP event pairs recorded
+on the launch stream around every 4th launch of the timed region.  `cpu_baseline` times the oracle
+(oracle/poker_oracle.c, the CPU restatement of the same policy+step) on the host cores, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+AGENTS = ["tight_aggressive", "heuristic_hands", "heuristic_hands", "loose_passive", "tight_aggressive",
+          "random", "loose_passive", "small_ball", "tight_aggressive"]   # reference config/pokerGPU.yaml:5-14
+BYTES_PER_TABLE_STEP = 453          # 173 + 28*P at P = 10
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CHECK_INTERVAL = 5                  # trainGPU.py:31
+TERMINATION_THRESHOLD = 0.8         # trainGPU.py:76
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--tables", type=int, default=65536, help="tables per GPU (weak scaling)")
+    ap.add_argument("--stop-rule", choices=["lagged", "sync"], default="lagged")
+    ap.add_argument("--launcher", choices=["native", "python"], default="native",
+                    help="native: 5-step chunks enqueued by pulse_poker_rollout; python: one ctypes call per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def native_types_for_episode(episode: int):
+    """Seat -> PULSE_AGENT_* for this episode: Q seat = episode % 10, list rotated like get_rotated_agents."""
+    from pulselib_amd.environments.Poker.utils import NATIVE_TYPE, PokerAgentType, get_rotated_agents
+    names = ["qlearning"] + AGENTS
+    types = [PokerAgentType(n) for n in names]
+    _, rotated, q_seat, rotation = get_rotated_agents(list(range(10)), types, episode_idx=episode, q_agent_idx=0)
+    native = [NATIVE_TYPE[t] for t in rotated]
+    native[q_seat] = NATIVE_TYPE[PokerAgentType.RANDOM]      # env-only: the learner's seat plays `random`
+    return native, q_seat, rotation
+
+
+class Runner:
+    """Episode loop of scripts/Poker/trainGPU.py:57-108 without the learner."""
+
+    def __init__(self, args, rank, world, device):
+        from pulselib_amd.environments.Poker import PokerGPU
+        self.args, self.rank, self.world, self.device = args, rank, world, device
+        self.N = args.tables
+        self.env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=self.N, starting_bbs=100,
+                            max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=20260401, table_id0=rank * self.N)
+        self.actions = torch.zeros(self.N, dtype=torch.long, device=device)
+        self.host_rng = random.Random(0)
+        self.episode = 0
+        self.global_step = 0           # Philox offset of the scripted policies
+        self.steps_in_episode = 0
+        self.side = torch.cuda.Stream(device=device)
+        self.counts_dev = torch.zeros(2, dtype=torch.int64, device=device)
+        self.counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.copy_events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pending = []              # chunk ids whose done-count copy is in flight
+        self._late_over = False
+        self.chunk = 0
+        self.episode_stats = torch.zeros(2, dtype=torch.float64, device=device)
+        self.new_episode()
+
+    def new_episode(self):
+        self.native, q_seat, rotation = native_types_for_episode(self.episode)
+        A = self.host_rng.randint(2, 10)                       # PokerGPU.py:77 (host RNG: no .item() sync)
+        self.env.reset(options={"rotation": rotation, "active_players": int(A), "q_agent_seat": q_seat})
+        self.episode += 1
+        self.steps_in_episode = 0
+        self.pending.clear()
+        self._late_over = False
+
+    def _count_done_async(self):
+        """#done tables of the current state -> pinned host memory on the side stream (no host sync)."""
+        env, slot = self.env, self.chunk & 1
+        while len(self.pending) >= 2:                      # bounded run-ahead: never reuse a slot still in flight
+            self.copy_events[self.pending[0] & 1].synchronize()
+            c = self.pending.pop(0)
+            self._late_over = self._late_over or (self.counts_host[c & 1].item() > TERMINATION_THRESHOLD * self.N)
+        self.counts_dev[slot].zero_()
+        env._lib.pulse_poker_stats(env.is_done.data_ptr(), None, None, self.N, self.counts_dev[slot:].data_ptr(), None,
+                                   torch.cuda.current_stream(self.device).cuda_stream)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            self.counts_host[slot:slot + 1].copy_(self.counts_dev[slot:slot + 1], non_blocking=True)
+            self.copy_events[slot].record(self.side)
+        self.pending.append(self.chunk)
+
+    def _episode_over(self, blocking):
+        """Stop rule of trainGPU.py:27-33 on the newest done-count that has reached the host."""
+        over, self._late_over = self._late_over, False
+        while self.pending:
+            c = self.pending[0]
+            ev = self.copy_events[c & 1]
+            if blocking:
+                ev.synchronize()
+            elif not ev.query():
+                break
+            self.pending.pop(0)
+            over = over or (self.counts_host[c & 1].item() > TERMINATION_THRESHOLD * self.N)
+        return over
+
+    def run_steps(self, k, time_every=0):
+        """Run exactly k counted steps (episodes roll over inside)."""
+        done = 0
+        env = self.env
+        while done < k:
+            n = min(CHECK_INTERVAL, k - done)
+            if self.args.launcher == "native":
+                env.rollout(self.native, self.actions, n, self.global_step, time_every=time_every)
+            else:
+                for i in range(n):
+                    env.policy_step(self.native, self.actions, self.global_step + i)
+            self.global_step += n
+            self.steps_in_episode += n
+            done += n
+            # trainGPU.py:99: the check happens at idx % 5 == 0, i.e. after steps 1, 6, 11, ...; chunks of five
+            # steps check after steps 5, 10, ... -- same cadence, first check four steps later.
+            self._count_done_async()
+            self.chunk += 1
+            if self._episode_over(blocking=self.args.stop_rule == "sync") or self.steps_in_episode >= 200:
+                self.end_episode()
+        return done
+
+    def end_episode(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            # the only cross-GPU exchange of the path: episode statistics (RCCL all-reduce over xGMI)
+            self.episode_stats[0] = self.env.is_done.sum()
+            self.episode_stats[1] = self.env._rewards[0].sum()
+            dist.all_reduce(self.episode_stats, async_op=True)
+        self.new_episode()
+
+
+def cpu_baseline(args, n_tables):
+    """Oracle (CPU restatement) timed on the host cores over a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as orc
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    env = orc.OraclePokerEnv(n_players=10, max_players=10, n_games=n_tables, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
+                             K=100, alpha=50, n_threads=threads)
+    rng = np.random.default_rng(0)
+    host_rng = random.Random(0)
+    actions = np.zeros(n_tables, dtype=np.int64)
+    # decks: the oracle takes injected decks; build one seeded set outside the timed region and reuse it
+    decks = np.argsort(rng.random((n_tables, 52)), axis=1).astype(np.int32) + 1
+    total_steps, elapsed, episode, gstep = 0, 0.0, 0, 0
+    while elapsed < args.cpu_seconds and episode < 200:
+        native, q_seat, rotation = native_types_for_episode(episode)
+        A = host_rng.randint(2, 10)
+        t0 = time.perf_counter()
+        env.reset(options={"rotation": rotation, "active_players": A, "q_agent_seat": q_seat, "prefixed_decks": decks})
+        idx = 0
+        while True:
+            env.policy_step(native, 20260401, gstep, actions)
+            gstep += 1
+            idx += 1
+            if idx % CHECK_INTERVAL == 0 and env.is_done.mean() > TERMINATION_THRESHOLD:
+                break
+            if idx >= 200:
+                break
+        elapsed += time.perf_counter() - t0
+        total_steps += idx * n_tables
+        episode += 1
+    return {"value": total_steps / elapsed, "unit": "env-steps/sec", "cores": threads, "kind": "port",
+            "sample": f"{episode} episodes x {n_tables} tables, {total_steps} table-steps in {elapsed:.1f} s "
+                      f"(oracle/poker_oracle.c policy+step, OpenMP over tables, stop rule as trainGPU.py:27-33)"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, args.tables)
+
+    runner = Runner(args, rank, world, device)
+    lib = runner.env._lib
+    runner.run_steps(args.warmup)
+    torch.cuda.synchronize()
+    s_ms, n_t = C.c_float(0), C.c_int32(0)
+    lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))     # drop warm-up samples
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ran = runner.run_steps(args.steps, time_every=4 if args.launcher == "native" else 0)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert ran == args.steps
+
+    lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_tables = args.tables * world
+        value = total_tables * args.steps / elapsed
+        roofline = None
+        if n_t.value > 0:
+            kernel_s = (s_ms.value / n_t.value) * 1e-3
+            achieved = BYTES_PER_TABLE_STEP * args.tables / kernel_s / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "poker_step_kernel<PH_STEP, POLICY>", "kernel_us": kernel_s * 1e6,
+                        "launches_timed": n_t.value, "algorithmic_bytes_per_launch": BYTES_PER_TABLE_STEP * args.tables}
+        out = {
+            "metric": "env-steps/sec (whole node), Poker batched tables", "value": value, "unit": "env-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"Poker {args.tables} tables/GPU x {world} GPU, 10 seats, config/pokerGPU.yaml opponents, "
+                                   f"env-only (policy+step fused), device-shuffled decks, active_players 2..10",
+                       "tables_per_gpu": args.tables, "n_players": 10, "stop_rule": args.stop_rule, "launcher": args.launcher,
+                       "episodes": runner.episode, "parallelism": f"tables sharded x{world}, no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

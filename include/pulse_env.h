@@ -137,6 +137,16 @@ int pulse_poker_policy(const float* obs, int32_t obs_stride, const int32_t* seat
 int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
                             uint64_t table_id0, int64_t* actions, float* rewards, void* stream);
 
+/* Roll-out: n_steps fused policy+step launches enqueued back to back from native code (no host work
+ * between launches).  v_even/v_odd are the two ping-pong views (is_done <-> is_done_out swapped);
+ * step i uses v_even / rewards_even when i is even.  Philox offset of step i = step_counter0 + i.
+ * time_every > 0: every time_every-th launch is bracketed by a HIP event pair on `stream`; read the
+ * summed kernel time with pulse_rollout_timing_collect() AFTER synchronising the stream. */
+int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
+                        uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
+                        float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stream);
+int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed);
+
 /* Episode statistics for the trainer's stop rule and returns (scripts/Poker/trainGPU.py:27-33,96):
  * stats device int64[2] += {#tables with is_done, 0}; fstats device double[1] += sum(rewards[mask]). */
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n,

@@ -178,6 +178,23 @@ class OraclePokerEnv:
         return self.obs, self.rewards, self.is_done.astype(bool), np.zeros(self.n_games, dtype=bool), \
             {"active_players": self.active_players, "stacks": self.stacks, "seat_idx": self.idx}
 
+    def policy(self, agent_types, seed, step_counter, actions, table_id0=0):
+        """build_actions with the scripted opponents (utils.py:108-123); fills `actions` in place."""
+        types = (C.c_uint8 * self.n_players)(*[int(x) for x in agent_types])
+        assert actions.dtype == np.int64 and actions.flags["C_CONTIGUOUS"]
+        s = self._struct()
+        lib().oracle_policy(C.byref(s), types, C.c_uint64(seed), C.c_uint64(step_counter), C.c_uint64(table_id0),
+                            actions.ctypes.data_as(C.c_void_p), C.c_int(self.n_threads))
+        return actions
+
+    def policy_step(self, agent_types, seed, step_counter, actions, table_id0=0):
+        types = (C.c_uint8 * self.n_players)(*[int(x) for x in agent_types])
+        s = self._struct()
+        lib().oracle_policy_step(C.byref(s), types, C.c_uint64(seed), C.c_uint64(step_counter), C.c_uint64(table_id0),
+                                 actions.ctypes.data_as(C.c_void_p), self.rewards.ctypes.data_as(C.c_void_p),
+                                 C.c_int(self.n_threads))
+        return self.obs, self.rewards, self.is_done.astype(bool)
+
     # per-table method-level entry points for white-box checks
     def _each(self, fn, *extra):
         s = self._struct()

@@ -417,3 +417,64 @@ void oracle_eval_hands(const int32_t* hr, int64_t hr_len, const int32_t* cards, 
         out[i] = (n_cards == 7) ? p : hr_at(&v, p);
     }
 }
+
+/* ---- scripted opponents: environments/Poker/utils.py:108-123 + Player.py:79-176 ----------------
+ * One table; c1,c2 = obs cols 5,6 (hole cards of the seat to act), pot = obs col 9.  Random picks
+ * come from Philox4x32-10(seed, table id, step counter) -- the stream the HIP policy kernel uses --
+ * so CPU and GPU roll-outs follow the same trajectory.  type: 0 external (untouched), 1 random,
+ * 2 heuristic_hands, 3 tight_aggressive, 4 loose_passive, 5 small_ball. */
+void oracle_philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset, uint32_t out[4]);
+
+static int rand_below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)n) >> 32); }
+
+int oracle_scripted_action(int type, int c1, int c2, int pot, const uint32_t rnd[4]) {
+    const int r1 = pymod(c1, 13), r2 = pymod(c2, 13);
+    const int d = r1 > r2 ? r1 - r2 : r2 - r1;
+    const int pair = r1 == r2;
+    int a = 0;
+    if (type == 1) a = rand_below(rnd[0], 13);                                        /* utils.py:121 */
+    else if (type == 2) {                                                             /* Player.py:85-102 */
+        int fold = r1 < 8 && r2 < 8;
+        int raise = (pair || r1 >= 10 || r2 >= 10) && !fold;
+        a = raise ? 2 + rand_below(rnd[0], 9) : 0;
+    } else if (type == 3) {                                                           /* Player.py:112-124 */
+        int fold = r1 < 7 && r2 < 7 && d > 5;
+        int raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
+        a = fold ? 0 : 1;
+        if (raise) a = 2 + 5 + rand_below(rnd[0], 4);
+    } else if (type == 4) {                                                           /* Player.py:134-149 */
+        int fold = r1 <= 4 && r2 <= 4 && d > 9;
+        int call = ((pair && r1 > 8) || (r1 >= 11 && r2 > 9) || (r2 >= 11 && r1 > 9)) && !fold;
+        float u = (float)(rnd[1] >> 8) * (1.0f / 16777216.0f);
+        int raise = (u > 0.9f) && call;
+        a = call ? 1 : 0;
+        if (raise) a = 2 + rand_below(rnd[0], 4);
+    } else if (type == 5) {                                                           /* Player.py:159-174 */
+        int fold = (r1 < 6 && r2 < 6 && pot > 30) || (r1 < 9 && r2 < 9 && pot > 80);
+        int raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
+        a = raise ? 2 + rand_below(rnd[0], 3) : 0;
+    }
+    return a;
+}
+
+/* build_actions over the batch from the observation buffer (utils.py:108-123) */
+void oracle_policy(const OraclePoker* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
+                   uint64_t table_id0, int64_t* actions, int n_threads) {
+    const int N = v->n_games;
+    #pragma omp parallel for num_threads(n_threads) schedule(static) if (n_threads > 1)
+    for (int t = 0; t < N; t++) {
+        const int type = agent_types[v->idx[t] & 15];
+        if (!type) continue;
+        const float* o = v->obs + (size_t)t * v->obs_size;
+        uint32_t rnd[4];
+        oracle_philox4x32(seed, table_id0 + (uint64_t)t, step_counter, rnd);
+        actions[t] = oracle_scripted_action(type, (int)o[5], (int)o[6], (int)o[9], rnd);
+    }
+}
+
+/* policy + step, the unit bench.py times as one env-step pass on the CPU */
+void oracle_policy_step(const OraclePoker* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
+                        uint64_t table_id0, int64_t* actions, float* rewards, int n_threads) {
+    oracle_policy(v, agent_types, seed, step_counter, table_id0, actions, n_threads);
+    oracle_step(v, actions, rewards, n_threads);
+}

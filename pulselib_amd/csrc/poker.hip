@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 
 #include "pulse_internal.h"
 
@@ -128,19 +129,71 @@ __device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot
 // ---------------------------------------------------------------- the fused step
 struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
 
-template <uint32_t PH, bool POLICY>
+// A table is owned by LPT adjacent lanes (LPT = 1, 2, 4, 8 or 16: a DPP quad/row fraction, never
+// straddling a wavefront); lane j of the group owns seats j, j+LPT, j+2*LPT, ... (SPL of them).
+// Per-table scalars are replicated in the group's lanes, so the scalar part of the state machine
+// costs 1/LPT wave-instructions per table; per-seat work is SPL unrolled iterations.  LPT = 4 is
+// the default: cross-seat reductions are two quad-permute DPP steps (no LDS), 16 tables share a
+// wavefront, and 65,536 tables still give 4 waves per SIMD to hide the gather latency.
+// Cross-lane steps are DPP modifiers on the VALU op (no LDS traffic): quad_perm inside a quad,
+// row rotations inside a 16-lane row.  Every lane of a table is active whenever one is (all branches
+// around these calls are table-uniform), so no step reads a disabled lane.
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;                               // quad_perm:[1,0,3,2] / [2,3,0,1]
+constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0x128;
+
+#define PULSE_GRP_REDUCE(NAME, TYPE, OP)                                                            \
+    template <int LPT> __device__ __forceinline__ TYPE NAME(TYPE v) {                                \
+        static_assert(LPT == 1 || LPT == 2 || LPT == 4 || LPT == 16, "unsupported lanes per table"); \
+        if (LPT == 2 || LPT == 4) { const TYPE o = (TYPE)dpp_mov<kQuadXor1>((int)v); v = OP(v, o); } \
+        if (LPT == 4) { const TYPE o = (TYPE)dpp_mov<kQuadXor2>((int)v); v = OP(v, o); }             \
+        if (LPT == 16) {                                                                             \
+            TYPE o = (TYPE)dpp_mov<kRowRor1>((int)v); v = OP(v, o);                                  \
+            o = (TYPE)dpp_mov<kRowRor2>((int)v); v = OP(v, o);                                       \
+            o = (TYPE)dpp_mov<kRowRor4>((int)v); v = OP(v, o);                                       \
+            o = (TYPE)dpp_mov<kRowRor8>((int)v); v = OP(v, o);                                       \
+        }                                                                                            \
+        return v;                                                                                    \
+    }
+#define PULSE_OP_OR(a, b) ((a) | (b))
+#define PULSE_OP_MIN(a, b) min((a), (b))
+#define PULSE_OP_MAX(a, b) max((a), (b))
+PULSE_GRP_REDUCE(grp_or, uint32_t, PULSE_OP_OR)
+PULSE_GRP_REDUCE(grp_imin, int, PULSE_OP_MIN)
+PULSE_GRP_REDUCE(grp_imax, int, PULSE_OP_MAX)
+// x mod A for x that is almost always within one period of [0, A): two conditional corrections,
+// integer division only on the (poked-state) slow path.
+__device__ __forceinline__ int mod_near(int x, int A) {
+    if ((uint32_t)(x + A) < (uint32_t)(3 * A)) { x += x < 0 ? A : 0; x -= x >= A ? A : 0; return x; }
+    return pymod(x, A);
+}
+__device__ __forceinline__ int first_after_near(uint32_t bits, int x, int A) {
+    const int xm = mod_near(x, A);
+    const uint32_t maskA = (1u << A) - 1u;
+    const uint32_t rot = ((bits >> (xm + 1)) | (bits << (A - 1 - xm))) & maskA;   // bit k <-> seat (xm+1+k)%A
+    if (!rot) return -1;
+    const int seat = xm + 1 + (__ffs((int)rot) - 1);
+    return seat >= A ? seat - A : seat;
+}
+// tanh rounded once from double: 1 - 2/(exp(2x)+1) (abs. error ~1e-16, far below the fp32 ulp)
+__device__ __forceinline__ float tanh_rn(float x) {
+    const double e2 = exp(2.0 * (double)x);
+    return (float)(1.0 - 2.0 / (e2 + 1.0));
+}
+
+template <uint32_t PH, bool POLICY, int LPT, int SPL>
 __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
                                                            const int32_t* __restrict__ actor_idx_in,
                                                            float* __restrict__ rewards, const PolicyArgs pa) {
+    static_assert(LPT * SPL >= 1 && LPT * SPL <= 16 * 16 && (LPT & (LPT - 1)) == 0, "bad table mapping");
     const int gt = blockIdx.x * kBlock + threadIdx.x;
-    const int t = gt >> 4;
-    const int s = gt & 15;
-    if (t >= v.n_games) return;   // whole 16-lane groups leave together
+    const int t = gt / LPT;
+    const int j = gt % LPT;
+    if (t >= v.n_games) return;   // whole lane groups leave together
     const int P = v.n_players, A = v.active_players;
-    const bool seat = s < P, inA = s < A;
     const int32_t* __restrict__ hr = v.hand_ranks;
     const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
-    const size_t row = (size_t)t * P + s;
+    const size_t row0 = (size_t)t * P;
 
     // ---- load (every load is independent: all in flight at once)
     int idx = v.idx[t], button = v.button[t], pot = v.pots[t], stage = v.stages[t], dpos = v.deck_positions[t];
@@ -148,20 +201,33 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     bool done = v.is_done[t] != 0;
     bool dirty = v.equity_dirty[t] != 0;
     int b0 = v.board[t * 5 + 0], b1 = v.board[t * 5 + 1], b2 = v.board[t * 5 + 2], b3 = v.board[t * 5 + 3], b4 = v.board[t * 5 + 4];
-    int stack = seat ? v.stacks[row] : 0, bet = seat ? v.current_round_bet[row] : 0;
-    int inv = seat ? v.total_invested[row] : 0, status = seat ? v.status[row] : PULSE_SITOUT;
-    int h0 = -1, h1 = -1;
-    if (seat) { const int2 h = *reinterpret_cast<const int2*>(v.hands + row * 2); h0 = h.x; h1 = h.y; }
-    float eq = inA ? v.equities[(size_t)t * A + s] : 0.5f;
+    int stack[SPL], bet[SPL], inv[SPL], status[SPL], h0[SPL], h1[SPL];
+    float eq[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int seat = j + LPT * k;
+        stack[k] = 0; bet[k] = 0; inv[k] = 0; status[k] = PULSE_SITOUT; h0[k] = -1; h1[k] = -1; eq[k] = 0.5f;
+        if (seat < P) {
+            stack[k] = v.stacks[row0 + seat]; bet[k] = v.current_round_bet[row0 + seat];
+            inv[k] = v.total_invested[row0 + seat]; status[k] = v.status[row0 + seat];
+            const int2 h = *reinterpret_cast<const int2*>(v.hands + (row0 + seat) * 2);
+            h0[k] = h.x; h1[k] = h.y;
+        }
+        if (seat < A) eq[k] = v.equities[(size_t)t * A + seat];
+    }
     long long act64 = 0;
     if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = actions[t];
     const float w1 = *v.w1, w2 = *v.w2;
     const int Kdiv = *v.K, alpha = *v.alpha;
 
+    // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
+#define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return grp_or<LPT>(m_); }())
+#define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)grp_or<LPT>(r_); }())
+
     // ---- capture (PokerGPU.py:530-539)
     const bool prev_done = done;
-    const int actor = (PH & PULSE_PH_CAPTURE) || !actor_idx_in ? idx : actor_idx_in[t];
-    int a_status = grp_bcast(status, actor), a_stack = grp_bcast(stack, actor), a_bet = grp_bcast(bet, actor);
+    const int actor = ((PH & PULSE_PH_CAPTURE) || !actor_idx_in ? idx : actor_idx_in[t]) & 15;
+    const int a_status = SEAT_PICK(status, actor), a_stack = SEAT_PICK(stack, actor), a_bet = SEAT_PICK(bet, actor);
     const bool has_legal_actor = a_status != PULSE_FOLDED && a_status != PULSE_ALLIN && a_status != PULSE_SITOUT && !prev_done;
     int prev_invested = a_bet;
     if (!(PH & PULSE_PH_CAPTURE)) prev_invested = v.prev_invested[t];
@@ -172,8 +238,9 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
         if (type != PULSE_AGENT_EXTERNAL) {
             const U4 rnd = philox4x32(pa.seed, pa.table_id0 + (uint64_t)t, pa.step_counter);
-            act64 = scripted_action(type, grp_bcast(h0, idx), grp_bcast(h1, idx), pot, rnd);
-            if (s == 0) actions[t] = act64;
+            const int seat_i = idx & 15;
+            act64 = scripted_action(type, SEAT_PICK(h0, seat_i), SEAT_PICK(h1, seat_i), pot, rnd);
+            if (j == 0) actions[t] = act64;
         }
     }
     const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
@@ -181,19 +248,31 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     // ---- 1) equities of dirty tables (PokerGPU.py:455-525)
     if (PH & PULSE_PH_EQUITY) {
         if (dirty) {
-            float e = 0.5f;
-            if (inA && stage >= 1 && stage <= 3) {
-                const int c5 = stage >= 2 ? b3 : 0, c6 = stage == 3 ? b4 : 0;
-                const float r = (float)walk7(hr, hr_len, h0, h1, b0, b1, b2, c5, c6);
-                e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
-                e = fminf(fmaxf(e, 0.0f), 1.0f);
+            const int c5 = stage >= 2 ? b3 : 0, c6 = stage == 3 ? b4 : 0;
+            const bool street = stage >= 1 && stage <= 3;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                const int seat = j + LPT * k;
+                float e = 0.5f;
+                if (seat < A && street) {
+                    const float r = (float)walk7(hr, hr_len, h0[k], h1[k], b0, b1, b2, c5, c6);
+                    e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
+                    e = fminf(fmaxf(e, 0.0f), 1.0f);
+                }
+                eq[k] = e;
+                if (seat < A) v.equities[(size_t)t * A + seat] = e;
             }
-            eq = e;
-            if (inA) v.equities[(size_t)t * A + s] = e;
             dirty = false;
         }
     }
-    const float e_actor = grp_bcastf(eq, actor);
+    float e_actor;
+    {
+        uint32_t r_ = 0;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == actor ? __float_as_uint(eq[k]) : 0u;
+        e_actor = __uint_as_float(grp_or<LPT>(r_));
+        if (actor >= LPT * SPL) e_actor = 0.5f;
+    }
 
     // ---- 2) execute the action of the seat to act (PokerGPU.py:230-303)
     if (PH & PULSE_PH_EXECUTE) {
@@ -224,12 +303,14 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
                 }
             }
             acted += 1;
-            if (s == (idx & 15)) { stack = n_stack; bet = n_bet; inv += n_inv_add; status = n_status; }
+#pragma unroll
+            for (int k = 0; k < SPL; ++k)
+                if (j + LPT * k == (idx & 15)) { stack[k] = n_stack; bet[k] = n_bet; inv[k] += n_inv_add; status[k] = n_status; }
         }
     }
 
-    const uint32_t act_bits = grp_ballot(status == PULSE_ACTIVE);
-    const uint32_t cont_bits = grp_ballot(status == PULSE_ACTIVE || status == PULSE_ALLIN);
+    const uint32_t act_bits = SEAT_BITS(status[k] == PULSE_ACTIVE);
+    const uint32_t cont_bits = SEAT_BITS(status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
     const int contenders = __popc(cont_bits);
 
     // ---- 3) next actor, round close, street transition (PokerGPU.py:547-616)
@@ -238,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         const bool all_acted = acted >= truly_active;
         bool round_over = done || truly_active == 0;
         const uint32_t maskA = (1u << A) - 1u;
-        const int next_seat = first_after(act_bits & maskA, idx, A);
+        const int next_seat = first_after_near(act_bits & maskA, idx, A);
         const bool has_next = next_seat >= 0;
         const bool closes = all_acted && (idx == agg || (has_next && next_seat == agg));
         round_over = round_over || !has_next || closes;
@@ -246,8 +327,10 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         const bool early_term = contenders <= 1 && round_over;
         if (early_term) done = true;
         if (round_over && !early_term && !done) {
-            lrs = 1; stage += 1; highest = 0; agg = pymod(button + 1, A); acted = 0; bet = 0;
-            const int first = first_after(act_bits & maskA, button, A);
+            lrs = 1; stage += 1; highest = 0; agg = mod_near(button + 1, A); acted = 0;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) bet[k] = 0;
+            const int first = first_after_near(act_bits & maskA, button, A);
             if (first >= 0) idx = first;
             if (stage > 3) { done = true; stage = 4; }
             else {
@@ -268,7 +351,9 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     const bool newly_done = (PH & PULSE_PH_CAPTURE) ? (done && !prev_done) : done;
     if (PH & PULSE_PH_FOLDWIN) {                                            // :331-338
         if (newly_done && contenders == 1) {
-            if (s == __ffs((int)cont_bits) - 1) stack += pot;
+            const int survivor = __ffs((int)cont_bits) - 1;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) if (j + LPT * k == survivor) stack[k] += pot;
             pot = 0;
         }
     }
@@ -290,33 +375,49 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
                 b4 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
                 dpos += 2;
             }
-            const bool eligible = inA && (status == PULSE_ACTIVE || status == PULSE_ALLIN);
-            int rank = INT_MIN;
-            if (eligible) rank = walk7(hr, hr_len, h0, h1, b0, b1, b2, b3, b4);
+            bool eligible[SPL]; int rank[SPL], payout[SPL];
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                eligible[k] = (j + LPT * k) < A && (status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
+                rank[k] = INT_MIN; payout[k] = 0;
+                if (eligible[k]) rank[k] = walk7(hr, hr_len, h0[k], h1[k], b0, b1, b2, b3, b4);
+            }
             // side pots, one layer per distinct commitment level (PokerGPU.py:340-378)
-            int payout = 0, prev_level = 0;
+            int prev_level = 0;
             for (int l = 0; l < A; ++l) {
-                const int level = grp_min(inA && inv > prev_level ? inv : INT_MAX);
+                int lv = INT_MAX;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] > prev_level) lv = min(lv, inv[k]);
+                const int level = grp_imin<LPT>(lv);
                 if (level == INT_MAX) break;
-                const bool contrib = inA && inv >= level;
-                const int n_contrib = __popc(grp_ballot(contrib));
-                const int best = grp_max(contrib && eligible ? rank : INT_MIN);
-                const bool win = contrib && eligible && rank == best;
-                const uint32_t win_bits = grp_ballot(win);
+                const int n_contrib = __popc(SEAT_BITS((j + LPT * k) < A && inv[k] >= level));
+                int bl = INT_MIN;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] >= level && eligible[k]) bl = max(bl, rank[k]);
+                const int best = grp_imax<LPT>(bl);
+                const uint32_t win_bits = SEAT_BITS((j + LPT * k) < A && inv[k] >= level && eligible[k] && rank[k] == best);
                 const int n_win = __popc(win_bits);
                 if (n_win > 0) {
                     const int layer_pot = (level - prev_level) * n_contrib;
                     const int share = layer_pot / n_win, rem = layer_pot - share * n_win;
-                    if (win) payout += share + (s == __ffs((int)win_bits) - 1 ? rem : 0);
+                    const int first_win = __ffs((int)win_bits) - 1;
+#pragma unroll
+                    for (int k = 0; k < SPL; ++k)
+                        if ((win_bits >> (j + LPT * k)) & 1u) payout[k] += share + ((j + LPT * k) == first_win ? rem : 0);
                 }
                 prev_level = level;
             }
-            stack += payout;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) stack[k] += payout[k];
             pot = 0; stage = 5;
         }
     }
     if (PH & PULSE_PH_CLEARDONE) {                                          // :625-628
-        if (done) { bet = 0; inv = 0; highest = 0; }
+        if (done) {
+            highest = 0;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) { bet[k] = 0; inv[k] = 0; }
+        }
     }
 
     // ---- 5) shaped reward (PokerGPU.py:305-329, :631-632)
@@ -332,49 +433,66 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         else if (action == 0) sv = __fmul_rn(__fsub_rn(o, e_actor), potf);
         else if (action >= 2) sv = __fmul_rn(__fsub_rn(e_actor, fair), potf);
         const float x = __fdiv_rn(__fadd_rn(__fmul_rn(w1, m), __fmul_rn(w2, sv)), (float)Kdiv);
-        float r = __fmul_rn((float)alpha, (float)tanh((double)x));
+        float r = __fmul_rn((float)alpha, tanh_rn(x));
         if ((PH & PULSE_PH_CAPTURE) && (!has_legal_actor || prev_done)) r = 0.0f;
-        if (s == 0) rewards[t] = r;
+        if (j == 0) rewards[t] = r;
     }
 
     // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
     if (PH & PULSE_PH_OBS) {
         float* __restrict__ o = v.obs + (size_t)t * v.obs_size;
-        const int n_h0 = grp_bcast(h0, idx), n_h1 = grp_bcast(h1, idx);
-        const int n_stack = grp_bcast(stack, idx), n_status = grp_bcast(status, idx), n_bet = grp_bcast(bet, idx);
-        if (s < 13) {
-            int hv;
-            switch (s) {
-            case 0: hv = b0; break; case 1: hv = b1; break; case 2: hv = b2; break; case 3: hv = b3; break;
-            case 4: hv = b4; break; case 5: hv = n_h0; break; case 6: hv = n_h1; break; case 7: hv = stage; break;
-            case 8: hv = pymod(idx - button, A); break; case 9: hv = pot; break; case 10: hv = highest - n_bet; break;
-            case 11: hv = n_stack; break; default: hv = n_status; break;
+        const int seat_i = idx & 15;
+        const int n_h0 = SEAT_PICK(h0, seat_i), n_h1 = SEAT_PICK(h1, seat_i);
+        const int n_stack = SEAT_PICK(stack, seat_i), n_status = SEAT_PICK(status, seat_i), n_bet = SEAT_PICK(bet, seat_i);
+        const int idxm = mod_near(idx, A);
+        const int pos = mod_near(idx - button, A);
+#pragma unroll
+        for (int c0 = 0; c0 < 13; c0 += LPT) {
+            const int c = c0 + j;
+            if (c < 13) {
+                int hv;
+                switch (c) {
+                case 0: hv = b0; break; case 1: hv = b1; break; case 2: hv = b2; break; case 3: hv = b3; break;
+                case 4: hv = b4; break; case 5: hv = n_h0; break; case 6: hv = n_h1; break; case 7: hv = stage; break;
+                case 8: hv = pos; break; case 9: hv = pot; break; case 10: hv = highest - n_bet; break;
+                case 11: hv = n_stack; break; default: hv = n_status; break;
+                }
+                o[c] = (float)hv;
             }
-            o[s] = (float)hv;
         }
-        // opponents: seat (idx+1+k)%A -> columns 13+3k..; lanes >= A zero-fill the padding slots
-        const int idxm = pymod(idx, A);
-        if (s < v.max_players && s != idxm) {
-            int k; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
-            if (inA) { k = s - idxm - 1; if (k < 0) k += A; f0 = (float)stack; f1 = (float)status; f2 = (float)bet; }
-            else k = s - 1;
-            float* dst = o + 13 + 3 * k;
-            dst[0] = f0; dst[1] = f1; dst[2] = f2;
+        // opponents: seat (idx+1+k)%A -> columns 13+3k..; seats >= A zero-fill the padding slots
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            const int seat = j + LPT * k;
+            if (seat < v.max_players && seat != idxm) {
+                int slot; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+                if (seat < A) { slot = seat - idxm - 1; if (slot < 0) slot += A; f0 = (float)stack[k]; f1 = (float)status[k]; f2 = (float)bet[k]; }
+                else slot = seat - 1;
+                float* dst = o + 13 + 3 * slot;
+                dst[0] = f0; dst[1] = f1; dst[2] = f2;
+            }
         }
     }
 
     // ---- store
-    if (seat) {
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.stacks[row] = stack;
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.current_round_bet[row] = bet;
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) v.total_invested[row] = inv;
-        if (PH & PULSE_PH_EXECUTE) v.status[row] = status;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int seat = j + LPT * k;
+        if (seat < P) {
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.stacks[row0 + seat] = stack[k];
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.current_round_bet[row0 + seat] = bet[k];
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) v.total_invested[row0 + seat] = inv[k];
+            if (PH & PULSE_PH_EXECUTE) v.status[row0 + seat] = status[k];
+        }
     }
-    if ((PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) && s < 5) {
-        const int bv = s == 0 ? b0 : s == 1 ? b1 : s == 2 ? b2 : s == 3 ? b3 : b4;
-        v.board[t * 5 + s] = bv;
+    if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
+#pragma unroll
+        for (int c0 = 0; c0 < 5; c0 += LPT) {
+            const int c = c0 + j;
+            if (c < 5) v.board[t * 5 + c] = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4;
+        }
     }
-    if (s == 0) {
+    if (j == 0) {
         if (PH & PULSE_PH_CAPTURE) { v.prev_stacks[t] = prev_stack; v.prev_invested[t] = prev_invested; }
         if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.pots[t] = pot;
         if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.highest[t] = highest;
@@ -384,6 +502,8 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) v.equity_dirty[t] = dirty ? 1 : 0;
         if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;
     }
+#undef SEAT_BITS
+#undef SEAT_PICK
 }
 
 // ---------------------------------------------------------------- standalone policy (build_actions)
@@ -564,10 +684,32 @@ uint64_t pack_types(const uint8_t* agent_types, int n_players) {
     return packed;
 }
 
+// Table -> lane mapping chosen per launch: PULSE_LPT env (1, 4, 16) overrides; default 4 lanes per table.
+int g_lpt = 0;
+int lanes_per_table() {
+    if (!g_lpt) {
+        const char* e = getenv("PULSE_LPT");
+        int x = e ? atoi(e) : 4;
+        g_lpt = (x == 1 || x == 4 || x == 16) ? x : 4;
+    }
+    return g_lpt;
+}
+
+template <uint32_t PH, bool POLICY>
+void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa,
+                 hipStream_t st) {
+    const int lpt = lanes_per_table();
+    const dim3 grid((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)), block(kBlock);
+    const int spl = (v.max_players + lpt - 1) / lpt;   // seats per lane needed to cover max_players (obs padding too)
+    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+}
+
 template <uint32_t PH>
 void launch_phase(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, hipStream_t st) {
-    hipLaunchKernelGGL((poker_step_kernel<PH, false>), dim3(grid_for_tables(v.n_games)), dim3(kBlock), 0, st, v, actions,
-                       actor_idx, rewards, PolicyArgs{0, 0, 0, 0});
+    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0}, st);
 }
 
 }  // namespace
@@ -588,8 +730,7 @@ int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types,
     if (!actions || !rewards || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_policy_step: null argument");
     if (v->n_games == 0) return 0;
     const PolicyArgs pa{pack_types(agent_types, v->n_players), seed, step_counter, table_id0};
-    hipLaunchKernelGGL((poker_step_kernel<PULSE_PH_STEP, true>), dim3(grid_for_tables(v->n_games)), dim3(kBlock), 0,
-                       (hipStream_t)stream, *v, actions, (const int32_t*)nullptr, rewards, pa);
+    launch_step<PULSE_PH_STEP, true>(*v, actions, nullptr, rewards, pa, (hipStream_t)stream);
     return finish_launch("pulse_poker_policy_step");
 }
 
@@ -649,6 +790,56 @@ int pulse_poker_eval_hands(const int32_t* hand_ranks, int32_t hand_ranks_len, co
     hipLaunchKernelGGL(poker_eval_kernel, dim3((n_hands + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
                        hand_ranks, (uint32_t)hand_ranks_len, cards, n_hands, n_cards, flop_double, out);
     return finish_launch("pulse_poker_eval_hands");
+}
+
+/* ---- roll-out: n_steps fused policy+step launches enqueued back to back from native code ---------- */
+namespace {
+constexpr int kMaxTimed = 4096;
+hipEvent_t g_ev_start[kMaxTimed], g_ev_stop[kMaxTimed];
+int g_ev_created = 0, g_ev_used = 0;
+}
+
+int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
+                        uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions, float* rewards_even,
+                        float* rewards_odd, int32_t n_steps, int32_t time_every, void* stream) {
+    if (int rc = check_view(v_even, "pulse_poker_rollout")) return rc;
+    if (int rc = check_view(v_odd, "pulse_poker_rollout")) return rc;
+    if (!actions || !rewards_even || !rewards_odd || !agent_types || n_steps < 0)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout: bad argument");
+    if (v_even->n_games == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t packed = pack_types(agent_types, v_even->n_players);
+    for (int i = 0; i < n_steps; ++i) {
+        const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
+        float* rw = (i & 1) ? rewards_odd : rewards_even;
+        const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0};
+        const bool timed = time_every > 0 && (i % time_every) == 0 && g_ev_used < kMaxTimed;
+        if (timed) {
+            if (g_ev_used >= g_ev_created) {
+                if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess || hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess)
+                    return pulse::fail(PULSE_ENODEVICE, "pulse_poker_rollout: hipEventCreate failed");
+                ++g_ev_created;
+            }
+            (void)hipEventRecord(g_ev_start[g_ev_used], st);
+        }
+        launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
+        if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); ++g_ev_used; }
+    }
+    return finish_launch("pulse_poker_rollout");
+}
+
+int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed) {
+    if (!sum_ms || !n_timed) return pulse::fail(PULSE_EINVAL, "pulse_rollout_timing_collect: null argument");
+    float total = 0.0f;
+    for (int i = 0; i < g_ev_used; ++i) {
+        float ms = 0.0f;
+        const hipError_t e = hipEventElapsedTime(&ms, g_ev_start[i], g_ev_stop[i]);
+        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_rollout_timing_collect (call it after a stream sync)");
+        total += ms;
+    }
+    *sum_ms = total; *n_timed = g_ev_used;
+    g_ev_used = 0;
+    return 0;
 }
 
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n, int64_t* stats,

@@ -240,10 +240,16 @@ class PokerGPU(_EnvBase):
         if seed is not None:
             self.seed = int(seed)
         options = options or {}
-        if options.get('active_players', False):
-            candidate_players = torch.randint(2, self.n_players + 1, (1,), device=self.device).item()
-        else:
-            candidate_players = self.n_players
+        ap = options.get('active_players', False)
+        if isinstance(ap, (bool, type(None))) or not isinstance(ap, int):
+            if ap:      # reference behaviour: sample on the device and sync once per episode (PokerGPU.py:76-77)
+                candidate_players = torch.randint(2, self.n_players + 1, (1,), device=self.device).item()
+            else:
+                candidate_players = self.n_players
+        else:           # extension: the caller sampled it (host RNG), no device sync
+            if not (2 <= ap <= self.n_players):
+                raise ValueError(f"active_players must be in [2, {self.n_players}], got {ap}")
+            candidate_players = ap
         q_seat = options.get('q_agent_seat', 0)
         self.active_players = int(max(candidate_players, q_seat + 1))
         A, N = self.active_players, self.n_games
@@ -308,6 +314,33 @@ class PokerGPU(_EnvBase):
         object.__setattr__(self, "_pp", pp)
         object.__setattr__(self, "is_done", self._done_bufs[pp])
         return self.obs, rewards, self.is_done, self.is_truncated, self.get_info()
+
+    def rollout(self, agent_types, actions, n_steps, step_counter0, time_every=0):
+        """`n_steps` fused policy+step launches enqueued back to back by the native library (no Python
+        between launches).  Equivalent to calling policy_step(agent_types, actions, step_counter0 + i)
+        for i in range(n_steps); returns what the last step returned."""
+        actions = self._actions(actions)
+        key = tuple(int(x) for x in agent_types)
+        types = self._types_cache.get(key)
+        if types is None:
+            if len(key) != self.n_players:
+                raise ValueError(f"agent_types must have {self.n_players} entries, got {len(key)}")
+            types = self._types_cache[key] = (C.c_uint8 * self.n_players)(*key)
+        if self._view_dirty:
+            self._build_views()
+        pp = self._pp
+        _native.check(self._lib.pulse_poker_rollout(C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types,
+                                                    self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
+                                                    actions.data_ptr(), self._rewards[pp].data_ptr(),
+                                                    self._rewards[1 - pp].data_ptr(), int(n_steps), int(time_every),
+                                                    self._stream()), "pulse_poker_rollout")
+        if n_steps <= 0:
+            return self.obs, self._rewards[pp], self.is_done, self.is_truncated, self.get_info()
+        last = pp if (n_steps - 1) % 2 == 0 else 1 - pp
+        new_pp = pp if n_steps % 2 == 0 else 1 - pp
+        object.__setattr__(self, "_pp", new_pp)
+        object.__setattr__(self, "is_done", self._done_bufs[new_pp])
+        return self.obs, self._rewards[last], self.is_done, self.is_truncated, self.get_info()
 
     # ------------------------------------------------------------------ white-box methods
     def _phases(self, phases, actions=None, actor_idx=None, rewards=None):

@@ -183,3 +183,72 @@ def test_device_table_digest_matches_golden(golden_dir):
     from pulselib_amd import handranks
     vec = np.load(golden_dir / "handranks_vectors.npz")
     assert hashlib.sha256(handranks.host_table().tobytes()).hexdigest() == str(vec["sha256"])
+
+
+@pytest.mark.parametrize("launcher", ["policy_step", "rollout", "policy_then_step"])
+def test_fused_policy_step_matches_oracle(oracle_table, launcher):
+    """Scripted opponents fused with the step (one launch) follow the oracle's policy+step trajectory
+    bit for bit: same Philox stream, same masks (Player.py:79-176), same transition."""
+    from oracle import oracle as orc
+    from pulselib_amd.environments.Poker.utils import launch_policy, set_policy_seed
+    N, P = 8192, 10
+    kw = dict(n_players=P, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
+    env = _gpu_env(seed=777, table_id0=5000, **kw)
+    ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
+    types = [0, 3, 2, 2, 4, 3, 1, 4, 5, 3]      # seat 0 external (caller's action), the rest pokerGPU.yaml's mix
+    rng = np.random.default_rng(3)
+    gstep = 11
+    for e, A in enumerate((10, 4, 8)):
+        decks = _seeded_decks(N, 99 + e)
+        env.reset(options={"active_players": A, "rotation": e, "prefixed_decks": decks})
+        ref.reset(options={"active_players": A, "rotation": e, "prefixed_decks": decks.numpy()})
+        s = 0
+        while s < 40:
+            ext = rng.integers(0, 13, N).astype(np.int64)
+            a_ref = ext.copy()
+            a_gpu = torch.from_numpy(ext.copy()).to(DEV)
+            if launcher == "rollout":
+                n = 4
+                # EXTERNAL seats re-read the same buffer every step of the chunk on both sides
+                env.rollout(types, a_gpu, n, gstep)
+                for i in range(n):
+                    ref.policy_step(types, 777, gstep + i, a_ref, table_id0=5000)
+                rew = env._rewards[1 - env._pp] if False else None
+            elif launcher == "policy_step":
+                n = 1
+                _, rew, _, _, _ = env.policy_step(types, a_gpu, gstep)
+                ref.policy_step(types, 777, gstep, a_ref, table_id0=5000)
+            else:
+                n = 1
+                set_policy_seed(777)
+                launch_policy(env.obs, a_gpu, env.idx, types, table_id0=5000, step_counter=gstep)
+                _, rew, _, _, _ = env.step(a_gpu)
+                ref.policy_step(types, 777, gstep, a_ref, table_id0=5000)
+            gstep += n
+            s += n
+            ctx = f"{launcher} e{e} step {s}"
+            np.testing.assert_array_equal(a_gpu.cpu().numpy(), a_ref, err_msg=ctx + " actions")
+            got = _snap(env)
+            assert_state_equal(got, ref.snapshot(), ctx=ctx)
+            np.testing.assert_array_equal(got["obs"], ref.obs, err_msg=ctx)
+            if rew is not None:
+                np.testing.assert_allclose(to_np(rew), ref.rewards, rtol=0, atol=reward_tol(50), err_msg=ctx)
+    assert to_np(env.is_done).mean() > 0.5
+
+
+def test_device_shuffle_gives_permutations():
+    env = _gpu_env(n_players=10, max_players=10, n_games=4096, seed=5)
+    env.reset()
+    d1 = env.decks.cpu().numpy().copy()
+    assert np.array_equal(np.sort(d1, axis=1), np.tile(np.arange(1, 53, dtype=np.int32), (4096, 1)))
+    np.testing.assert_array_equal(env.hands.cpu().numpy().reshape(4096, 20), d1[:, :20])
+    env.reset()
+    d2 = env.decks.cpu().numpy()
+    assert np.array_equal(np.sort(d2, axis=1), np.tile(np.arange(1, 53, dtype=np.int32), (4096, 1)))
+    assert (d1 != d2).mean() > 0.9                 # a new episode draws new decks
+    # every card is (roughly) equally likely in every position: chi-square-ish bound on the top card
+    counts = np.bincount(d1[:, 0], minlength=53)[1:]
+    assert counts.min() > 30 and counts.max() < 140   # mean 78.8 for 4096 decks
+    env2 = _gpu_env(n_players=10, max_players=10, n_games=4096, seed=5)
+    env2.reset()
+    np.testing.assert_array_equal(env2.decks.cpu().numpy(), d1)    # same seed, same tables -> same decks
