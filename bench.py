@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--stop-rule", choices=["lagged", "sync"], default="lagged")
     ap.add_argument("--launcher", choices=["native", "python"], default="native",
                     help="native: 5-step chunks enqueued by pulse_poker_rollout; python: one ctypes call per step")
+    ap.add_argument("--max-episode-steps", type=int, default=40,
+                    help="episode cap: the reference's close-on-aggressor rule livelocks tables whose last ACTIVE seat "
+                         "keeps calling against all-ins (SURVEY.md A.3), so >20 %% of tables may never finish; its "
+                         "published runs average 31-35 steps per episode (results/PokerGPU/runs/run_2..8.yaml)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -151,7 +155,7 @@ class Runner:
             # steps check after steps 5, 10, ... -- same cadence, first check four steps later.
             self._count_done_async()
             self.chunk += 1
-            if self._episode_over(blocking=self.args.stop_rule == "sync") or self.steps_in_episode >= 200:
+            if self._episode_over(blocking=self.args.stop_rule == "sync") or self.steps_in_episode >= self.args.max_episode_steps:
                 self.end_episode()
         return done
 
@@ -174,6 +178,7 @@ def cpu_baseline(args, n_tables):
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    threads = int(os.environ.get("PULSE_CPU_THREADS", min(threads, 16)))   # the 1-GPU box's CPU share is 16 cores
     env = orc.OraclePokerEnv(n_players=10, max_players=10, n_games=n_tables, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
                              K=100, alpha=50, n_threads=threads)
     rng = np.random.default_rng(0)
@@ -194,14 +199,15 @@ def cpu_baseline(args, n_tables):
             idx += 1
             if idx % CHECK_INTERVAL == 0 and env.is_done.mean() > TERMINATION_THRESHOLD:
                 break
-            if idx >= 200:
+            if idx >= args.max_episode_steps:
                 break
         elapsed += time.perf_counter() - t0
         total_steps += idx * n_tables
         episode += 1
     return {"value": total_steps / elapsed, "unit": "env-steps/sec", "cores": threads, "kind": "port",
             "sample": f"{episode} episodes x {n_tables} tables, {total_steps} table-steps in {elapsed:.1f} s "
-                      f"(oracle/poker_oracle.c policy+step, OpenMP over tables, stop rule as trainGPU.py:27-33)"}
+                      f"(oracle/poker_oracle.c policy+step, OpenMP over tables, stop rule as trainGPU.py:27-33, "
+                      f"cap {args.max_episode_steps} steps/episode)"}
 
 
 def main():
@@ -266,7 +272,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"Poker {args.tables} tables/GPU x {world} GPU, 10 seats, config/pokerGPU.yaml opponents, "
                                    f"env-only (policy+step fused), device-shuffled decks, active_players 2..10",
-                       "tables_per_gpu": args.tables, "n_players": 10, "stop_rule": args.stop_rule, "launcher": args.launcher,
+                       "tables_per_gpu": args.tables, "n_players": 10, "stop_rule": args.stop_rule, "max_episode_steps": args.max_episode_steps, "launcher": args.launcher,
                        "episodes": runner.episode, "parallelism": f"tables sharded x{world}, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -147,6 +147,10 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
                         float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stream);
 int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed);
 
+/* Diagnostic only (tools/ablate_step.py): fused policy+step with phases compiled out, to price them. */
+int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* actions, float* rewards, uint64_t types_packed,
+                       uint64_t step_counter, void* stream);
+
 /* Episode statistics for the trainer's stop rule and returns (scripts/Poker/trainGPU.py:27-33,96):
  * stats device int64[2] += {#tables with is_done, 0}; fstats device double[1] += sum(rewards[mask]). */
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n,

@@ -246,3 +246,75 @@ def philox4x32(seed: int, subseq: int, offset: int) -> np.ndarray:
     out = np.zeros(4, dtype=np.uint32)
     lib().oracle_philox4x32(C.c_uint64(seed), C.c_uint64(subseq), C.c_uint64(offset), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Blackjack / 2048 / Particle2D oracles (oracle/envs_oracle.c)
+class _BJStruct(C.Structure):
+    _fields_ = [("batch_size", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "decks", "deck_positions", "players_cards", "players_card_idx", "player_card_sums",
+        "dealer_cards", "dealer_card_idx", "dealer_upcard", "dealer_card_sums",
+        "terminated", "has_ace", "dealer_has_ace", "rewards", "obs")]
+
+
+class OracleBlackjack:
+    """Numpy twin of the reference BlackJack (environments/blackjack/blackjack.py) over liboracle.so."""
+
+    I32 = ("deck_positions", "players_card_idx", "player_card_sums", "dealer_card_idx", "dealer_upcard", "dealer_card_sums", "rewards")
+    U8 = ("terminated", "has_ace", "dealer_has_ace")
+
+    def __init__(self, batch_size):
+        B = self.batch_size = batch_size
+        self.decks = np.zeros((B, 52), dtype=np.int32)
+        for n in self.I32:
+            setattr(self, n, np.zeros(B, dtype=np.int32))
+        for n in self.U8:
+            setattr(self, n, np.zeros(B, dtype=np.uint8))
+        self.players_cards = np.zeros((B, 20), dtype=np.int32)
+        self.dealer_cards = np.zeros((B, 20), dtype=np.int32)
+        self.obs = np.zeros((B, 3), dtype=np.int32)
+
+    def _struct(self):
+        s = _BJStruct()
+        s.batch_size = self.batch_size
+        for n in ("decks", "players_cards", "dealer_cards", "obs") + self.I32 + self.U8:
+            setattr(s, n, getattr(self, n).ctypes.data)
+        return s
+
+    def reset(self, decks):
+        self.decks = np.ascontiguousarray(decks, dtype=np.int32).copy()
+        s = self._struct()
+        lib().oracle_blackjack_reset(C.byref(s))
+        return self.obs
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int64)
+        s = self._struct()
+        lib().oracle_blackjack_step(C.byref(s), actions.ctypes.data_as(C.c_void_p))
+        return self.obs, self.rewards, self.terminated.astype(bool)
+
+
+def tfe_reset(boards, total_score, n, seed, board_id0=0):
+    lib().oracle_tfe_reset(boards.ctypes.data_as(C.c_void_p), total_score.ctypes.data_as(C.c_void_p), C.c_int(boards.shape[0]),
+                           C.c_int(n), C.c_uint64(seed), C.c_uint64(board_id0))
+
+
+def tfe_step(boards, total_score, actions, rewards, dones, n, seed, step_counter, board_id0=0):
+    actions = np.ascontiguousarray(actions, dtype=np.int64)
+    lib().oracle_tfe_step(boards.ctypes.data_as(C.c_void_p), total_score.ctypes.data_as(C.c_void_p),
+                          actions.ctypes.data_as(C.c_void_p), rewards.ctypes.data_as(C.c_void_p),
+                          dones.ctypes.data_as(C.c_void_p), C.c_int(boards.shape[0]), C.c_int(n), C.c_uint64(seed),
+                          C.c_uint64(board_id0), C.c_uint64(step_counter))
+
+
+def particle2d_step(state, action, steps, dt, max_steps):
+    n = state.shape[0]
+    obs = np.zeros_like(state)
+    rewards = np.zeros(n, dtype=np.float32)
+    term = np.zeros(n, dtype=np.uint8)
+    action = np.ascontiguousarray(action, dtype=np.float32)
+    lib().oracle_particle2d_step(state.ctypes.data_as(C.c_void_p), action.ctypes.data_as(C.c_void_p),
+                                 steps.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p),
+                                 rewards.ctypes.data_as(C.c_void_p), term.ctypes.data_as(C.c_void_p), C.c_int(n),
+                                 C.c_float(dt), C.c_int(max_steps))
+    return obs, rewards, term.astype(bool)

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void particle2d_step_kernel(float4* __restr
     a.x = fminf(fmaxf(a.x, -1.0f), 1.0f); a.y = fminf(fmaxf(a.y, -1.0f), 1.0f);       // :23
     s.z = __fadd_rn(s.z, __fmul_rn(a.x, dt)); s.w = __fadd_rn(s.w, __fmul_rn(a.y, dt)); // :24
     s.x = __fadd_rn(s.x, __fmul_rn(s.z, dt)); s.y = __fadd_rn(s.y, __fmul_rn(s.w, dt)); // :25
-    const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(s.x, s.x), __fmul_rn(s.y, s.y))); // :26
+    const float dist = sqrtf(__fadd_rn(__fmul_rn(s.x, s.x), __fmul_rn(s.y, s.y)));      // :26 (IEEE sqrt: __fsqrt_rn is the native approximation)
     const float pen = __fmul_rn(0.001f, __fadd_rn(__fmul_rn(a.x, a.x), __fmul_rn(a.y, a.y)));
     const int st = steps[i] + 1;                                                        // :28
     state[i] = s; obs_out[i] = s;                                                       // :30 (clone)

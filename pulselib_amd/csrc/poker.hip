@@ -760,6 +760,31 @@ int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* 
     return finish_launch("pulse_poker_phases");
 }
 
+/* Diagnostic (tools/ablate_step.py): the fused policy+step with some phases compiled out, 4 lanes per
+ * table.  Results are NOT a valid transition; used only to price phases. */
+int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* actions, float* rewards, uint64_t types_packed,
+                       uint64_t step_counter, void* stream) {
+    if (int rc = check_view(v, "pulse_poker_ablate")) return rc;
+    const dim3 grid((unsigned)(((long long)v->n_games * 4 + kBlock - 1) / kBlock)), block(kBlock);
+    const PolicyArgs pa{types_packed, 1, step_counter, 0};
+    hipStream_t st = (hipStream_t)stream;
+#define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 4, 3>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa); break;
+    switch (phases) {
+    PULSE_ABL(PULSE_PH_STEP)
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_EQUITY)
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_SHOWDOWN)
+    PULSE_ABL(PULSE_PH_STEP & ~(PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN))
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_REWARD)
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_OBS)
+    PULSE_ABL(PULSE_PH_STEP & ~(PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN | PULSE_PH_REWARD))
+    PULSE_ABL(PULSE_PH_STEP & ~(PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN | PULSE_PH_REWARD | PULSE_PH_OBS))
+    PULSE_ABL(PULSE_PH_CAPTURE)
+    default: return pulse::fail(PULSE_EINVAL, "pulse_poker_ablate: mask not instantiated");
+    }
+#undef PULSE_ABL
+    return finish_launch("pulse_poker_ablate");
+}
+
 int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream) {
     if (int rc = check_view(v, "pulse_poker_reset")) return rc;
     if (!o || !o->decks_out) return pulse::fail(PULSE_EINVAL, "pulse_poker_reset: null options / decks_out");
