@@ -15,7 +15,7 @@ finished tables included (trainGPU.py:108).  Resets run inside the timed region 
 
 Prints ONE JSON line (rank 0).  `roofline` prices the fused step kernel: algorithmic bytes per launch
 (453 B per table-step) over the kernel's mean duration from HIP event pairs recorded
-on the launch stream around every 4th launch of the timed region.  `cpu_baseline` times the oracle
+on the launch stream around every 5-launch chunk of the timed region (kernel boundaries included).  `cpu_baseline` times the oracle
 (oracle/poker_oracle.c, the CPU restatement of the same policy+step) on the host cores, rank 0 at N=1 only.
 """
 from __future__ import annotations
@@ -90,6 +90,7 @@ class Runner:
         self.counts_dev = torch.zeros(2, dtype=torch.int64, device=device)
         self.counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()
         self.copy_events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.counts_seen = [0, 0]      # cumulative done-counts already consumed per slot
         self.pending = []              # chunk ids whose done-count copy is in flight
         self._late_over = False
         self.chunk = 0
@@ -102,7 +103,9 @@ class Runner:
         self.env.reset(options={"rotation": rotation, "active_players": int(A), "q_agent_seat": q_seat})
         self.episode += 1
         self.steps_in_episode = 0
-        self.pending.clear()
+        while self.pending:            # keep the cumulative counters consistent across episodes
+            self.copy_events[self.pending[0] & 1].synchronize()
+            self._pop_count()
         self._late_over = False
 
     def _count_done_async(self):
@@ -110,9 +113,8 @@ class Runner:
         env, slot = self.env, self.chunk & 1
         while len(self.pending) >= 2:                      # bounded run-ahead: never reuse a slot still in flight
             self.copy_events[self.pending[0] & 1].synchronize()
-            c = self.pending.pop(0)
-            self._late_over = self._late_over or (self.counts_host[c & 1].item() > TERMINATION_THRESHOLD * self.N)
-        self.counts_dev[slot].zero_()
+            self._late_over = self._late_over or self._pop_count()
+        # counts_dev[slot] is cumulative (pulse_poker_stats adds): no memset kernel in the loop
         env._lib.pulse_poker_stats(env.is_done.data_ptr(), None, None, self.N, self.counts_dev[slot:].data_ptr(), None,
                                    torch.cuda.current_stream(self.device).cuda_stream)
         ready = torch.cuda.Event()
@@ -133,9 +135,15 @@ class Runner:
                 ev.synchronize()
             elif not ev.query():
                 break
-            self.pending.pop(0)
-            over = over or (self.counts_host[c & 1].item() > TERMINATION_THRESHOLD * self.N)
+            over = over or self._pop_count()
         return over
+
+    def _pop_count(self):
+        c = self.pending.pop(0)
+        total = int(self.counts_host[c & 1].item())
+        n_done = total - self.counts_seen[c & 1]
+        self.counts_seen[c & 1] = total
+        return n_done > TERMINATION_THRESHOLD * self.N
 
     def run_steps(self, k, time_every=0):
         """Run exactly k counted steps (episodes roll over inside)."""

@@ -72,6 +72,17 @@ typedef struct PulsePokerView {
     float *equities, *obs;
     const float *w1, *w2;
     const int32_t *K, *alpha;
+    /* Optional evaluation cache (all four NULL = disabled), owned by the caller like the rest, opaque to
+     * it: pulse_poker_reset walks the table once per episode (board first, which reaches the same table
+     * state as the reference's hole-cards-first order for any distinct cards) and stores, per table, the
+     * board it will deal (pre_board [N], packed cards + valid bit) and, per seat, the hole cards used
+     * (pre_hands [N,P]), the three street equities (pre_eq [N,3,P], PokerGPU.py:455-525) and the 7-card
+     * rank (pre_rank [N,P], PokerGPU.py:437-444).  The step kernel uses an entry only if the cards it
+     * finds in `board` / `hands` at that moment are exactly the cached ones, else it does the reference's
+     * literal gather chain -- so poked states stay bit-exact and the common path needs no table gathers. */
+    int32_t *pre_board, *pre_hands;
+    float *pre_eq;
+    int32_t *pre_rank;
 } PulsePokerView;
 
 /* Phase bits for pulse_poker_phases: the white-box methods the reference's tests call directly. */
@@ -140,8 +151,9 @@ int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types,
 /* Roll-out: n_steps fused policy+step launches enqueued back to back from native code (no host work
  * between launches).  v_even/v_odd are the two ping-pong views (is_done <-> is_done_out swapped);
  * step i uses v_even / rewards_even when i is even.  Philox offset of step i = step_counter0 + i.
- * time_every > 0: every time_every-th launch is bracketed by a HIP event pair on `stream`; read the
- * summed kernel time with pulse_rollout_timing_collect() AFTER synchronising the stream. */
+ * time_every > 0: the chunk of n_steps launches is bracketed by ONE HIP event pair on `stream`; read the
+ * summed time and the number of launches it covers with pulse_rollout_timing_collect() AFTER
+ * synchronising the stream (mean per launch = sum / launches, kernel boundaries included). */
 int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
                         float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stream);

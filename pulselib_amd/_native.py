@@ -40,7 +40,8 @@ class PokerView(C.Structure):
             "is_done", "is_done_out", "equity_dirty",
             "stacks", "current_round_bet", "total_invested", "status",
             "hands", "board", "decks", "equities", "obs",
-            "w1", "w2", "K", "alpha")]
+            "w1", "w2", "K", "alpha",
+            "pre_board", "pre_hands", "pre_eq", "pre_rank")]
     )
 
 

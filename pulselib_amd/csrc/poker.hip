@@ -72,6 +72,24 @@ __device__ __forceinline__ int walk7(const int32_t* __restrict__ hr, uint32_t le
     return p;
 }
 
+// ---------------------------------------------------------------- evaluation cache tags
+// pre_board: five 6-bit cards (the board this episode will deal) | valid bit 30.
+// pre_hands: two 6-bit hole cards | valid bit 12.  A cached value is used only when the cards found
+// in state at that moment are in 1..52 and equal the cached ones, so it is the value the reference's
+// literal chain would produce (the table state after a set of distinct cards does not depend on order).
+constexpr uint32_t kPreBoardValid = 1u << 30, kPreHandsValid = 1u << 12;
+__device__ __forceinline__ bool card_ok(int c) { return (uint32_t)(c - 1) < 52u; }
+__device__ __forceinline__ uint32_t pack_board(int b0, int b1, int b2, int b3, int b4) {
+    return (uint32_t)(b0 & 63) | (uint32_t)(b1 & 63) << 6 | (uint32_t)(b2 & 63) << 12 | (uint32_t)(b3 & 63) << 18 | (uint32_t)(b4 & 63) << 24;
+}
+__device__ __forceinline__ uint32_t pack_hand(int h0, int h1) { return (uint32_t)(h0 & 63) | (uint32_t)(h1 & 63) << 6 | kPreHandsValid; }
+// n_cards of the current board (3, 4 or 5) are dealt, valid and equal to the cached ones
+__device__ __forceinline__ bool board_matches(uint32_t tag, int n_cards, int b0, int b1, int b2, int b3, int b4) {
+    const uint32_t mask = (1u << (6 * n_cards)) - 1u;
+    const bool in_range = card_ok(b0) && card_ok(b1) && card_ok(b2) && (n_cards < 4 || card_ok(b3)) && (n_cards < 5 || card_ok(b4));
+    return (tag & kPreBoardValid) && in_range && ((pack_board(b0, b1, b2, b3, b4) ^ tag) & mask) == 0;
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct U4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset) {
@@ -219,6 +237,16 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = actions[t];
     const float w1 = *v.w1, w2 = *v.w2;
     const int Kdiv = *v.K, alpha = *v.alpha;
+    uint32_t pre_tag = 0;
+    if ((PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board) pre_tag = (uint32_t)v.pre_board[t];
+    // next street's cards, fetched now so the dependent deck read overlaps the policy / betting logic
+    int nx0 = 0, nx1 = 0, nx2 = 0;
+    if (PH & PULSE_PH_ADVANCE) {
+        const int32_t* dk = v.decks + (size_t)t * 52;
+        nx0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+        nx1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
+        nx2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+    }
 
     // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
 #define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return grp_or<LPT>(m_); }())
@@ -250,14 +278,24 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         if (dirty) {
             const int c5 = stage >= 2 ? b3 : 0, c6 = stage == 3 ? b4 : 0;
             const bool street = stage >= 1 && stage <= 3;
+            const bool cached_board = street && board_matches(pre_tag, stage + 2, b0, b1, b2, b3, b4);
 #pragma unroll
             for (int k = 0; k < SPL; ++k) {
                 const int seat = j + LPT * k;
                 float e = 0.5f;
                 if (seat < A && street) {
-                    const float r = (float)walk7(hr, hr_len, h0[k], h1[k], b0, b1, b2, c5, c6);
-                    e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
-                    e = fminf(fmaxf(e, 0.0f), 1.0f);
+                    bool hit = false;
+                    if (cached_board) {       // both cache reads are independent single hops
+                        const uint32_t ph = (uint32_t)v.pre_hands[row0 + seat];
+                        const float pe = v.pre_eq[((size_t)t * 3 + (stage - 1)) * P + seat];
+                        hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
+                        e = pe;
+                    }
+                    if (!hit) {               // the reference's literal seven-gather chain
+                        const float r = (float)walk7(hr, hr_len, h0[k], h1[k], b0, b1, b2, c5, c6);
+                        e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
+                        e = fminf(fmaxf(e, 0.0f), 1.0f);
+                    }
                 }
                 eq[k] = e;
                 if (seat < A) v.equities[(size_t)t * A + seat] = e;
@@ -334,14 +372,9 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
             if (first >= 0) idx = first;
             if (stage > 3) { done = true; stage = 4; }
             else {
-                const int32_t* dk = v.decks + (size_t)t * 52;
-                if (stage == 1) {
-                    b0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
-                    b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
-                    b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
-                    dpos += 4;
-                } else if (stage == 2) { b3 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0; dpos += 2; }
-                else { b4 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0; dpos += 2; }
+                if (stage == 1) { b0 = nx0; b1 = nx1; b2 = nx2; dpos += 4; }     // burn + flop (:601-604)
+                else if (stage == 2) { b3 = nx0; dpos += 2; }                    // burn + turn (:607-610)
+                else { b4 = nx0; dpos += 2; }                                    // burn + river (:613-616)
                 dirty = true;
             }
         }
@@ -376,11 +409,22 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
                 dpos += 2;
             }
             bool eligible[SPL]; int rank[SPL], payout[SPL];
+            const bool cached_board = board_matches(pre_tag, 5, b0, b1, b2, b3, b4);
 #pragma unroll
             for (int k = 0; k < SPL; ++k) {
-                eligible[k] = (j + LPT * k) < A && (status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
+                const int seat = j + LPT * k;
+                eligible[k] = seat < A && (status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
                 rank[k] = INT_MIN; payout[k] = 0;
-                if (eligible[k]) rank[k] = walk7(hr, hr_len, h0[k], h1[k], b0, b1, b2, b3, b4);
+                if (eligible[k]) {
+                    bool hit = false;
+                    if (cached_board) {
+                        const uint32_t ph = (uint32_t)v.pre_hands[row0 + seat];
+                        const int pr = v.pre_rank[row0 + seat];
+                        hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
+                        rank[k] = pr;
+                    }
+                    if (!hit) rank[k] = walk7(hr, hr_len, h0[k], h1[k], b0, b1, b2, b3, b4);
+                }
             }
             // side pots, one layer per distinct commitment level (PokerGPU.py:340-378)
             int prev_level = 0;
@@ -589,6 +633,40 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     // instruction has returned for all its lanes by then: no lane overwrites a seat unread.
     int h0 = -1, h1 = -1;
     if (inA) { h0 = deck_s[g][2 * s]; h1 = deck_s[g][2 * s + 1]; }                     // :112-114
+    // evaluation cache for the episode (include/pulse_env.h: pre_*): walk the table board-first once
+    if (v.pre_board) {
+        const int f0 = deck_s[g][2 * A + 1], f1 = deck_s[g][2 * A + 2], f2 = deck_s[g][2 * A + 3];   // burn, flop
+        const int f3 = deck_s[g][2 * A + 5], f4 = deck_s[g][2 * A + 7];                               // burn, turn, burn, river
+        unsigned long long m = 0;
+        uint32_t bad = 0;
+        if (inA) { bad = !(card_ok(h0) && card_ok(h1)); m = (1ull << (h0 & 63)) | (1ull << (h1 & 63)); }
+        for (int x = 1; x < kLanes; x <<= 1) { m |= __shfl_xor(m, x, kLanes); bad |= (uint32_t)__shfl_xor((int)bad, x, kLanes); }
+        const bool board_ok = card_ok(f0) && card_ok(f1) && card_ok(f2) && card_ok(f3) && card_ok(f4);
+        m |= (1ull << (f0 & 63)) | (1ull << (f1 & 63)) | (1ull << (f2 & 63)) | (1ull << (f3 & 63)) | (1ull << (f4 & 63));
+        const bool valid = !bad && board_ok && __popcll(m) == 2 * A + 5;    // 2A+5 distinct cards in 1..52
+        const int32_t* __restrict__ hr = v.hand_ranks;
+        const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
+        if (valid && inA) {
+            int p3 = 53;
+            p3 = hr_at(hr, hr_len, p3 + f0); p3 = hr_at(hr, hr_len, p3 + f1); p3 = hr_at(hr, hr_len, p3 + f2);
+            const int p4 = hr_at(hr, hr_len, p3 + f3);
+            const int p5 = hr_at(hr, hr_len, p4 + f4);
+            const int q5 = hr_at(hr, hr_len, hr_at(hr, hr_len, p3 + h0) + h1);
+            const int q6 = hr_at(hr, hr_len, hr_at(hr, hr_len, p4 + h0) + h1);
+            const int r7 = hr_at(hr, hr_len, hr_at(hr, hr_len, p5 + h0) + h1);
+            const float vf = (float)hr_at(hr, hr_len, hr_at(hr, hr_len, q5));               // :521
+            const float vt = (float)hr_at(hr, hr_len, q6);                                  // :500
+            float ef = __fdiv_rn(__fsub_rn(vf, 74359.0f), 749420.0f);                       // :523
+            float et = __fdiv_rn(__fsub_rn(vt, 4109.0f), 32765.0f);                         // :502
+            float er = __fdiv_rn(__fsub_rn((float)r7, 4109.0f), 32765.0f);                  // :481
+            ef = fminf(fmaxf(ef, 0.0f), 1.0f); et = fminf(fmaxf(et, 0.0f), 1.0f); er = fminf(fmaxf(er, 0.0f), 1.0f);
+            float* pe = v.pre_eq + (size_t)t * 3 * P;
+            pe[s] = ef; pe[P + s] = et; pe[2 * P + s] = er;
+            v.pre_rank[row] = r7;
+        }
+        if (seat) v.pre_hands[row] = (valid && inA) ? (int32_t)pack_hand(h0, h1) : 0;
+        if (s == 0) v.pre_board[t] = valid ? (int32_t)(pack_board(f0, f1, f2, f3, f4) | kPreBoardValid) : 0;
+    }
     const int button = o.first ? 0 : pymod(v.button[t] + 1, A);                         // :121
     int sb, bb, idx;
     if (A == 2) { sb = button; bb = pymod(button + 1, A); idx = button; }               // :123-125,:131
@@ -822,6 +900,7 @@ namespace {
 constexpr int kMaxTimed = 4096;
 hipEvent_t g_ev_start[kMaxTimed], g_ev_stop[kMaxTimed];
 int g_ev_created = 0, g_ev_used = 0;
+int g_ev_launches[kMaxTimed];
 }
 
 int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
@@ -834,22 +913,23 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     if (v_even->n_games == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t packed = pack_types(agent_types, v_even->n_players);
+    // time_every > 0: bracket the whole chunk of launches with one HIP event pair on the launch stream
+    const bool timed = time_every > 0 && n_steps > 0 && g_ev_used < kMaxTimed;
+    if (timed) {
+        if (g_ev_used >= g_ev_created) {
+            if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess || hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess)
+                return pulse::fail(PULSE_ENODEVICE, "pulse_poker_rollout: hipEventCreate failed");
+            ++g_ev_created;
+        }
+        (void)hipEventRecord(g_ev_start[g_ev_used], st);
+    }
     for (int i = 0; i < n_steps; ++i) {
         const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
         float* rw = (i & 1) ? rewards_odd : rewards_even;
         const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0};
-        const bool timed = time_every > 0 && (i % time_every) == 0 && g_ev_used < kMaxTimed;
-        if (timed) {
-            if (g_ev_used >= g_ev_created) {
-                if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess || hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess)
-                    return pulse::fail(PULSE_ENODEVICE, "pulse_poker_rollout: hipEventCreate failed");
-                ++g_ev_created;
-            }
-            (void)hipEventRecord(g_ev_start[g_ev_used], st);
-        }
         launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
-        if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); ++g_ev_used; }
     }
+    if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); g_ev_launches[g_ev_used] = n_steps; ++g_ev_used; }
     return finish_launch("pulse_poker_rollout");
 }
 
@@ -862,7 +942,9 @@ int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed) {
         if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_rollout_timing_collect (call it after a stream sync)");
         total += ms;
     }
-    *sum_ms = total; *n_timed = g_ev_used;
+    int launches = 0;
+    for (int i = 0; i < g_ev_used; ++i) launches += g_ev_launches[i];
+    *sum_ms = total; *n_timed = launches;
     g_ev_used = 0;
     return 0;
 }

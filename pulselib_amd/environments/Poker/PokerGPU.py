@@ -15,6 +15,7 @@ Differences a caller can observe (all deliberate):
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -49,7 +50,8 @@ _BOOL_SCALARS = ("is_done", "equity_dirty")
 _ROWS = ("stacks", "current_round_bet", "total_invested", "status")
 _TRACKED = frozenset(_I32_SCALARS + _BOOL_SCALARS + _ROWS + ("hands", "board", "decks", "equities", "obs",
                                                              "w1", "w2", "K", "alpha", "hand_ranks",
-                                                             "active_players", "n_players", "n_games", "max_players"))
+                                                             "active_players", "n_players", "n_games", "max_players",
+                                                             "use_eval_cache"))
 
 
 class PokerGPU(_EnvBase):
@@ -93,6 +95,7 @@ class PokerGPU(_EnvBase):
         self.seed = int(seed)
         self.table_id0 = int(table_id0)
         self.episode = 0
+        self.use_eval_cache = os.environ.get("PULSE_EVAL_CACHE", "1") != "0"
 
         self.raise_fractions = torch.tensor([0.25, 0.33, 0.50, 0.75, 1.00, 1.50, 2.00, 3.00, 4.00], device=device)
         self.obs_size = 13 + ((self.max_players - 1) * 3)
@@ -121,6 +124,11 @@ class PokerGPU(_EnvBase):
         self.equities = self._equities_store[:N * P].view(N, P)
         self.obs = torch.zeros((N, self.obs_size), dtype=torch.float32, device=device)
         self._rewards = [torch.zeros(N, dtype=torch.float32, device=device) for _ in range(2)]
+        # evaluation cache filled by the reset kernel (include/pulse_env.h: pre_*); internal, not reference state
+        self._pre_board = torch.zeros(N, **i32)
+        self._pre_hands = torch.zeros((N, P), **i32)
+        self._pre_eq = torch.zeros((N, 3, P), dtype=torch.float32, device=device)
+        self._pre_rank = torch.zeros((N, P), **i32)
 
         # constants / scratch names the reference exposes (PokerGPU.py:61-68,138-155)
         self.g = torch.arange(N, device=device)
@@ -190,6 +198,11 @@ class PokerGPU(_EnvBase):
         ptr["equities"] = self.equities.data_ptr()
         for name, dt in (("w1", torch.float32), ("w2", torch.float32), ("K", torch.int32), ("alpha", torch.int32)):
             ptr[name] = self._as_state(name, dt, ()).data_ptr()
+        use_cache = self.use_eval_cache
+        ptr["pre_board"] = self._pre_board.data_ptr() if use_cache else None
+        ptr["pre_hands"] = self._pre_hands.data_ptr() if use_cache else None
+        ptr["pre_eq"] = self._pre_eq.data_ptr() if use_cache else None
+        ptr["pre_rank"] = self._pre_rank.data_ptr() if use_cache else None
         hr = self._as_state("hand_ranks", torch.int32, None)
         cur = self._as_state("is_done", torch.bool, (N,))
         if cur.data_ptr() == self._is_done_alt.data_ptr():
