@@ -163,6 +163,10 @@ int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed);
 int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* actions, float* rewards, uint64_t types_packed,
                        uint64_t step_counter, void* stream);
 
+/* Diagnostic only (tools/pmc_calibrate.py): stream n_words dwords, one dword per lane, read (write=0) or
+ * written (write=1), to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE on a known byte count. */
+int pulse_calib_stream(int32_t* buf, uint64_t n_words, int32_t write, void* stream);
+
 /* Episode statistics for the trainer's stop rule and returns (scripts/Poker/trainGPU.py:27-33,96):
  * stats device int64[2] += {#tables with is_done, 0}; fstats device double[1] += sum(rewards[mask]). */
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n,

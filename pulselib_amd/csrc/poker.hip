@@ -248,6 +248,16 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         nx2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
     }
 
+    // values as loaded: only what a step changes is written back (a table's seat rows change in one or
+    // two cells per step; writing all of them back doubles the store traffic)
+    const int idx_in = idx, pot_in = pot, stage_in = stage, dpos_in = dpos, highest_in = highest, agg_in = agg,
+              acted_in = acted, lrs_in = lrs;
+    const bool dirty_in = dirty;
+    int stack_in[SPL], bet_in[SPL], inv_in[SPL], status_in[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) { stack_in[k] = stack[k]; bet_in[k] = bet[k]; inv_in[k] = inv[k]; status_in[k] = status[k]; }
+    const int b0_in = b0, b1_in = b1, b2_in = b2, b3_in = b3, b4_in = b4;
+
     // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
 #define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return grp_or<LPT>(m_); }())
 #define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)grp_or<LPT>(r_); }())
@@ -518,33 +528,42 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         }
     }
 
-    // ---- store
+    // ---- store (changed words only)
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int seat = j + LPT * k;
         if (seat < P) {
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.stacks[row0 + seat] = stack[k];
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.current_round_bet[row0 + seat] = bet[k];
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) v.total_invested[row0 + seat] = inv[k];
-            if (PH & PULSE_PH_EXECUTE) v.status[row0 + seat] = status[k];
+            if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) && stack[k] != stack_in[k]) v.stacks[row0 + seat] = stack[k];
+            if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) && bet[k] != bet_in[k]) v.current_round_bet[row0 + seat] = bet[k];
+            if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) && inv[k] != inv_in[k]) v.total_invested[row0 + seat] = inv[k];
+            if ((PH & PULSE_PH_EXECUTE) && status[k] != status_in[k]) v.status[row0 + seat] = status[k];
         }
     }
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
 #pragma unroll
         for (int c0 = 0; c0 < 5; c0 += LPT) {
             const int c = c0 + j;
-            if (c < 5) v.board[t * 5 + c] = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4;
+            const int bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4;
+            const int bi = c == 0 ? b0_in : c == 1 ? b1_in : c == 2 ? b2_in : c == 3 ? b3_in : b4_in;
+            if (c < 5 && bv != bi) v.board[t * 5 + c] = bv;
         }
     }
     if (j == 0) {
         if (PH & PULSE_PH_CAPTURE) { v.prev_stacks[t] = prev_stack; v.prev_invested[t] = prev_invested; }
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.pots[t] = pot;
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.highest[t] = highest;
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { v.agg[t] = agg; v.acted[t] = acted; v.last_raise_size[t] = lrs; }
-        if (PH & PULSE_PH_ADVANCE) v.idx[t] = idx;
-        if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { v.stages[t] = stage; v.deck_positions[t] = dpos; }
-        if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) v.equity_dirty[t] = dirty ? 1 : 0;
-        if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;
+        if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) && pot != pot_in) v.pots[t] = pot;
+        if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) && highest != highest_in) v.highest[t] = highest;
+        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) {
+            if (agg != agg_in) v.agg[t] = agg;
+            if (acted != acted_in) v.acted[t] = acted;
+            if (lrs != lrs_in) v.last_raise_size[t] = lrs;
+        }
+        if ((PH & PULSE_PH_ADVANCE) && idx != idx_in) v.idx[t] = idx;
+        if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
+            if (stage != stage_in) v.stages[t] = stage;
+            if (dpos != dpos_in) v.deck_positions[t] = dpos;
+        }
+        if ((PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) && dirty != dirty_in) v.equity_dirty[t] = dirty ? 1 : 0;
+        if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;      // ping-pong buffer: always written
     }
 #undef SEAT_BITS
 #undef SEAT_PICK
@@ -730,6 +749,19 @@ __global__ __launch_bounds__(kBlock) void poker_stats_kernel(const uint8_t* __re
     }
 }
 
+// ---------------------------------------------------------------- PMC calibration (diagnostic)
+// Streams `n_words` dwords with this library's access shape -- one dword per lane, lanes on consecutive
+// addresses -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count
+// (MI355X_MICROARCH.md, HBM section: widths other than 16 B/lane are uncalibrated on gfx950).
+__global__ __launch_bounds__(kBlock) void calib_read_kernel(const int32_t* __restrict__ src, size_t n_words, int32_t* __restrict__ out) {
+    int acc = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_words; i += (size_t)gridDim.x * kBlock) acc += src[i];
+    if (acc == 0x7fffffff) out[0] = acc;      // keeps the loads alive without a store in the common case
+}
+__global__ __launch_bounds__(kBlock) void calib_write_kernel(int32_t* __restrict__ dst, size_t n_words, int32_t value) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_words; i += (size_t)gridDim.x * kBlock) dst[i] = value;
+}
+
 // ---------------------------------------------------------------- host side
 int check_view(const PulsePokerView* v, const char* who) {
     if (!v) return pulse::fail(PULSE_EINVAL, "null PulsePokerView");
@@ -768,7 +800,7 @@ int lanes_per_table() {
     if (!g_lpt) {
         const char* e = getenv("PULSE_LPT");
         int x = e ? atoi(e) : 4;
-        g_lpt = (x == 1 || x == 4 || x == 16) ? x : 4;
+        g_lpt = (x == 1 || x == 2 || x == 4 || x == 16) ? x : 4;
     }
     return g_lpt;
 }
@@ -781,6 +813,8 @@ void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor
     const int spl = (v.max_players + lpt - 1) / lpt;   // seats per lane needed to cover max_players (obs padding too)
     if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
     else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
     else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
     else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
 }
@@ -861,6 +895,14 @@ int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* action
     }
 #undef PULSE_ABL
     return finish_launch("pulse_poker_ablate");
+}
+
+int pulse_calib_stream(int32_t* buf, uint64_t n_words, int32_t write, void* stream) {
+    if (!buf || n_words == 0) return pulse::fail(PULSE_EINVAL, "pulse_calib_stream: bad argument");
+    const dim3 grid(2048), block(kBlock);
+    if (write) hipLaunchKernelGGL(calib_write_kernel, grid, block, 0, (hipStream_t)stream, buf, (size_t)n_words, 7);
+    else hipLaunchKernelGGL(calib_read_kernel, grid, block, 0, (hipStream_t)stream, buf, (size_t)n_words, buf);
+    return finish_launch("pulse_calib_stream");
 }
 
 int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream) {
