@@ -218,6 +218,21 @@ def cpu_baseline(args, n_tables):
                       f"cap {args.max_episode_steps} steps/episode)"}
 
 
+def recorded_traffic(tables):
+    """HBM-side bytes per launch of the fused step kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN/step_kernel_profile.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected by the
+    dword-stream calibration recorded with them).  None if no summary matches this workload."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile.json")):
+        try:
+            d = json.loads(f.read_text())
+            if int(d.get("tables_per_launch", -1)) == tables:
+                best = float(d["traffic_bytes_per_launch"])
+        except Exception:
+            pass
+    return best
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -272,7 +287,7 @@ def main():
             kernel_s = (s_ms.value / n_t.value) * 1e-3
             achieved = BYTES_PER_TABLE_STEP * args.tables / kernel_s / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "poker_step_kernel<PH_STEP, POLICY>", "kernel_us": kernel_s * 1e6,
+                        "traffic": recorded_traffic(args.tables), "kernel": "poker_step_kernel<PH_STEP, POLICY>", "kernel_us": kernel_s * 1e6,
                         "launches_timed": n_t.value, "algorithmic_bytes_per_launch": BYTES_PER_TABLE_STEP * args.tables}
         out = {
             "metric": "env-steps/sec (whole node), Poker batched tables", "value": value, "unit": "env-steps/sec",

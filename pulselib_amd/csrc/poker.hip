@@ -146,6 +146,13 @@ __device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot
 
 // ---------------------------------------------------------------- the fused step
 struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
+#ifndef PULSE_TANH_F32
+#define PULSE_TANH_F32 0
+#endif
+#ifndef PULSE_PREFETCH_DECK
+#define PULSE_PREFETCH_DECK 0
+#endif
+constexpr bool kPrefetchDeck = PULSE_PREFETCH_DECK != 0;   // 1: read the next street's cards up front (latency) ; 0: only on a deal (bytes)
 
 // A table is owned by LPT adjacent lanes (LPT = 1, 2, 4, 8 or 16: a DPP quad/row fraction, never
 // straddling a wavefront); lane j of the group owns seats j, j+LPT, j+2*LPT, ... (SPL of them).
@@ -195,8 +202,12 @@ __device__ __forceinline__ int first_after_near(uint32_t bits, int x, int A) {
 }
 // tanh rounded once from double: 1 - 2/(exp(2x)+1) (abs. error ~1e-16, far below the fp32 ulp)
 __device__ __forceinline__ float tanh_rn(float x) {
+#if PULSE_TANH_F32
+    return tanhf(x);
+#else
     const double e2 = exp(2.0 * (double)x);
     return (float)(1.0 - 2.0 / (e2 + 1.0));
+#endif
 }
 
 template <uint32_t PH, bool POLICY, int LPT, int SPL>
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     if ((PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board) pre_tag = (uint32_t)v.pre_board[t];
     // next street's cards, fetched now so the dependent deck read overlaps the policy / betting logic
     int nx0 = 0, nx1 = 0, nx2 = 0;
-    if (PH & PULSE_PH_ADVANCE) {
+    if ((PH & PULSE_PH_ADVANCE) && kPrefetchDeck) {
         const int32_t* dk = v.decks + (size_t)t * 52;
         nx0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
         nx1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
@@ -382,6 +393,14 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
             if (first >= 0) idx = first;
             if (stage > 3) { done = true; stage = 4; }
             else {
+                if (!kPrefetchDeck) {
+                    const int32_t* dk = v.decks + (size_t)t * 52;
+                    nx0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    if (stage == 1) {
+                        nx1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
+                        nx2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                    }
+                }
                 if (stage == 1) { b0 = nx0; b1 = nx1; b2 = nx2; dpos += 4; }     // burn + flop (:601-604)
                 else if (stage == 2) { b3 = nx0; dpos += 2; }                    // burn + turn (:607-610)
                 else { b4 = nx0; dpos += 2; }                                    // burn + river (:613-616)
@@ -805,18 +824,25 @@ int lanes_per_table() {
     return g_lpt;
 }
 
+int g_lds_pad = -1;
+int lds_pad() {      // experiment knob: dynamic LDS bytes per workgroup, only to cap workgroups per CU
+    if (g_lds_pad < 0) { const char* e = getenv("PULSE_LDS_PAD"); g_lds_pad = e ? atoi(e) : 0; }
+    return g_lds_pad;
+}
+
 template <uint32_t PH, bool POLICY>
 void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa,
                  hipStream_t st) {
     const int lpt = lanes_per_table();
     const dim3 grid((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)), block(kBlock);
+    const int pad = lds_pad();
     const int spl = (v.max_players + lpt - 1) / lpt;   // seats per lane needed to cover max_players (obs padding too)
-    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
-    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
-    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
 }
 
 template <uint32_t PH>

@@ -1,0 +1,144 @@
+"""Episode driver with the reference trainer's loop contract (scripts/Poker/trainGPU.py:36-145):
+
+  * seat rotation per episode (get_rotated_agents), reset options {rotation, active_players, q_agent_seat};
+  * per step: actions.fill_(0) -> build_actions -> env.step -> learner.train_step on
+    `q_mask & ~terminated` evaluated BEFORE `terminated |= dones` (trainGPU.py:85-86);
+  * stop rule every 5th step at > 80 % terminated (trainGPU.py:27-33); `total_steps += n_games * idx`
+    (trainGPU.py:108) -- finished tables count, as in every number the reference publishes;
+  * run summary with the reference's keys (`sps`, `total_steps`, ...; utils/benchmarking/benchmarking.py:84-100).
+
+The learner is whatever object sits at the QLEARNING seat (`get_actions`, `train_step`): the reference's
+PokerQNetwork runs unchanged on PyTorch-ROCm; `SimpleQNetwork` below is a minimal stand-in with the same
+interface.  With N > 1 ranks each process drives its own shard and episode sums are all-reduced (RCCL)."""
+from __future__ import annotations
+
+import time
+from pathlib import Path
+
+import torch
+
+from ..environments.Poker.utils import PokerAgentType, build_actions, get_rotated_agents
+from ..sharding import EpisodeStats
+
+CHECK_INTERVAL = 5            # trainGPU.py:31
+TERMINATION_THRESHOLD = 0.8   # trainGPU.py:76
+
+
+def _should_stop_loop(step_idx: int, terminated: torch.Tensor, termination_threshold, check_interval: int = CHECK_INTERVAL) -> bool:
+    return step_idx % check_interval == 0 and bool(terminated.float().mean() > termination_threshold)
+
+
+def train_agent(env, agents, agent_types, episodes, n_games, device, results_dir=None, config=None, plotter=None,
+                benchmarker=None, build_actions_fn=build_actions, max_episode_steps=None, reduce_stats=True):
+    config = config or {}
+    total_steps = 0
+    start_time = time.time()
+    scores, reward_scores = [], []
+    actions = torch.zeros(n_games, dtype=torch.long, device=device)
+    q_agent_idx = agent_types.index(PokerAgentType.QLEARNING)
+    q_agent = agents[q_agent_idx]
+    stats = EpisodeStats(device)
+
+    for episode in range(episodes):
+        rotated_agents, rotated_types, q_seat, rotations = get_rotated_agents(agents, agent_types, episode_idx=episode,
+                                                                              q_agent_idx=q_agent_idx)
+        state, info = env.reset(options={"rotation": rotations, "active_players": True, "q_agent_seat": q_seat})
+        initial_stacks = info["stacks"][:, q_seat].clone()
+        terminated = torch.zeros(n_games, dtype=torch.bool, device=device)
+        episode_reward_tensor = torch.tensor(0.0, device=device)
+        termination_threshold = torch.tensor(TERMINATION_THRESHOLD, device=device)
+        idx = 0
+        while True:
+            actions.fill_(0)
+            q_mask = info["seat_idx"] == q_seat
+            build_actions_fn(state, actions, info["seat_idx"], rotated_agents, rotated_types, device)
+            # the env reuses its observation buffer (PokerGPU.py:633): keep the pre-step rows for the learner
+            state_before = state[q_mask & ~terminated].clone() if hasattr(q_agent, "train_step") else None
+            next_state, rewards, dones, truncated, info = env.step(actions)
+            del truncated
+            active_games = q_mask & ~terminated
+            terminated |= dones
+            if state_before is not None and active_games.any():
+                q_agent.train_step(states=state_before, actions=actions[active_games], rewards=rewards[active_games],
+                                   next_states=next_state[active_games], dones=dones[active_games])
+            episode_reward_tensor += rewards[active_games].sum()
+            state = next_state
+            if _should_stop_loop(idx, terminated, termination_threshold):
+                break
+            idx += 1
+            if max_episode_steps is not None and idx >= max_episode_steps:
+                break
+        final_stacks = info["stacks"][:, q_seat]
+        stats.set(terminated.sum(), episode_reward_tensor, (final_stacks - initial_stacks).sum())
+        totals = (stats.all_reduce_async() if reduce_stats else stats).wait()
+        reward_scores.append(float(totals[1].item()))
+        scores.append(float(totals[2].item()))
+        total_steps += n_games * idx
+
+    end_time = time.time()
+    elapsed = end_time - start_time
+    summary = {"env": config.get("ENV_ID", "Pulse-Poker-GPU-v1"), "total_steps": total_steps, "start_time": start_time,
+               "end_time": end_time, "total_training_seconds": elapsed, "sps": total_steps / elapsed if elapsed > 0 else 0.0,
+               "episode_rewards": reward_scores, "episode_profits": scores, "config": dict(config)}
+    if plotter is not None and results_dir is not None:
+        plotter.plot_learning_curve(scores=reward_scores, file_path=str(Path(results_dir) / "rewards_learning_curve"), window_size=10,
+                                    title="Poker Q-Learning - Total Reward per Episode Batch")
+        plotter.plot_learning_curve(scores=scores, file_path=str(Path(results_dir) / "total_chips_curve"), window_size=10,
+                                    title="Poker Q-Learning - Total Chip Profit per Episode Batch")
+    if benchmarker is not None:
+        benchmarker.create_benchmark_file(env_name=summary["env"], episodes_return=reward_scores, start_time=start_time,
+                                          end_time=end_time, total_steps=total_steps, config=config)
+    return summary
+
+
+class SimpleQNetwork(torch.nn.Module):
+    """Minimal learner with the interface the driver needs (the reference's PokerQNetwork,
+    environments/Poker/Player.py:178-298, is the real one and runs unchanged on PyTorch-ROCm)."""
+
+    def __init__(self, device, gamma=0.95, state_dim=40, action_dim=13, lr=2e-4, epsilon=0.1):
+        super().__init__()
+        self.device, self.gamma, self.epsilon = device, gamma, epsilon
+        self.network = torch.nn.Sequential(torch.nn.Linear(state_dim, 128), torch.nn.GELU(), torch.nn.Linear(128, 64), torch.nn.GELU(),
+                                           torch.nn.Linear(64, action_dim)).to(device)
+        self.optimizer = torch.optim.AdamW(self.parameters(), lr=lr)
+
+    def get_actions(self, states):
+        with torch.inference_mode():
+            greedy = self.network(states).argmax(dim=1)
+            explore = torch.rand(states.shape[0], device=states.device) < self.epsilon
+            return torch.where(explore, torch.randint(0, 13, (states.shape[0],), device=states.device), greedy)
+
+    def train_step(self, states, actions, rewards, next_states, dones):
+        valid = (states[:, 12] == 0) | (states[:, 12] == 2)           # Player.py:261
+        if not valid.any():
+            return 0.0
+        states, actions, rewards, next_states, dones = states[valid], actions[valid], rewards[valid], next_states[valid], dones[valid]
+        q = self.network(states).gather(1, actions.unsqueeze(1)).squeeze(1)
+        with torch.no_grad():
+            target = rewards + self.gamma * self.network(next_states).max(dim=1).values * (~dones).float()
+        loss = torch.nn.functional.mse_loss(q, target)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
+        self.optimizer.step()
+        return loss
+
+
+def main():
+    import yaml
+    from ..environments.Poker import PokerGPU, load_gpu_agents
+    cfg = yaml.safe_load((Path(__file__).resolve().parent.parent / "config" / "pokerGPU.yaml").read_text())
+    device = torch.device("cuda", torch.cuda.current_device())
+    n_games = int(cfg["N_GAMES"])
+    agents, types = load_gpu_agents(device, cfg["NUM_PLAYERS"], cfg["AGENTS"], cfg["STARTING_BBS"], cfg["ACTION_SPACE"])
+    agents.insert(0, SimpleQNetwork(device, gamma=cfg["GAMMA"], state_dim=cfg["STATE_SPACE"], lr=float(cfg["LEARNING_RATE"])))
+    types.insert(0, PokerAgentType.QLEARNING)
+    env = PokerGPU(device=device, agents=agents, n_players=cfg["NUM_PLAYERS"] + 1, n_games=n_games, starting_bbs=cfg["STARTING_BBS"],
+                   w1=cfg["W1"], w2=cfg["W2"], K=cfg["K"], alpha=cfg["ALPHA"], seed=cfg.get("SEED", 0))
+    out = train_agent(env, agents, types, int(cfg["EPISODES"]), n_games, device, config=cfg,
+                      max_episode_steps=cfg.get("MAX_EPISODE_STEPS"))
+    print({k: out[k] for k in ("total_steps", "total_training_seconds", "sps")})
+
+
+if __name__ == "__main__":
+    main()
