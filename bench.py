@@ -195,7 +195,7 @@ def cpu_baseline(args, n_tables):
     # decks: the oracle takes injected decks; build one seeded set outside the timed region and reuse it
     decks = np.argsort(rng.random((n_tables, 52)), axis=1).astype(np.int32) + 1
     total_steps, elapsed, episode, gstep = 0, 0.0, 0, 0
-    while elapsed < args.cpu_seconds and episode < 200:
+    while elapsed < args.cpu_seconds and episode < 5000:
         native, q_seat, rotation = native_types_for_episode(episode)
         A = host_rng.randint(2, 10)
         t0 = time.perf_counter()

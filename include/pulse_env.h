@@ -193,6 +193,26 @@ int pulse_tfe_step(int32_t* boards, int64_t* total_score, const int64_t* actions
                    uint8_t* dones, int32_t n_boards, int32_t n, uint64_t seed, uint64_t board_id0,
                    uint64_t step_counter, void* stream);                                        /* :152-189 */
 
+/* ---- Tabular Q-learning for the batched 2048 roll-out -------------------------------------------
+ * Replaces utils/numba.py:5-21 (epsilon-greedy) and :25-39 (update) + the defaultdict of
+ * agents/TemperalDifference/QLearningNumba.py:10-37.  keys: device uint64[capacity] (0 = empty),
+ * values: device double[capacity,4], both zero-initialised by the caller; capacity and region_slots are
+ * powers of two.  region_slots > 0: board g owns slots [g*region_slots, (g+1)*region_slots) (independent
+ * learners, race-free); 0: one table shared by all boards (updates applied with a CAS loop). */
+typedef struct PulseQTable {
+    uint64_t* keys;
+    double* values;
+    uint64_t capacity, region_slots;
+} PulseQTable;
+/* state lookup/insert + epsilon-greedy: actions int64[B] out, slots int64[B] out (-1 = region full) */
+int pulse_qtable_select(const PulseQTable* q, const int32_t* boards, int32_t n_boards, int32_t n, double epsilon,
+                        uint64_t seed, uint64_t board_id0, uint64_t step_counter, int64_t* actions, int64_t* slots,
+                        void* stream);
+/* q[s][a] += alpha * ((terminal ? r : r + gamma * max q[s']) - q[s][a]) for every board */
+int pulse_qtable_update(const PulseQTable* q, const int64_t* slots, const int64_t* actions, const int32_t* rewards,
+                        const int32_t* next_boards, const uint8_t* terminal, int32_t n_boards, int32_t n, double alpha,
+                        double gamma, void* stream);
+
 /* ---- Particle2D (environments/Particle2D/Particle2D.py:22-30) ---------------------------------- */
 int pulse_particle2d_step(float* state, const float* action, int32_t* steps, float* obs_out, float* rewards,
                           uint8_t* terminated, int32_t n, float dt, int32_t max_steps, void* stream);

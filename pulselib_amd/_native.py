@@ -51,6 +51,10 @@ class PokerResetOpts(C.Structure):
                 ("prefixed_decks", C.c_void_p), ("decks_out", C.c_void_p)]
 
 
+class QTable(C.Structure):
+    _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("capacity", C.c_uint64), ("region_slots", C.c_uint64)]
+
+
 class BlackjackView(C.Structure):
     _fields_ = [("batch_size", C.c_int32)] + [(n, C.c_void_p) for n in (
         "decks", "deck_positions", "players_cards", "players_card_idx", "player_card_sums",
@@ -79,6 +83,8 @@ SYMBOLS = {
     "pulse_blackjack_step": (C.c_int, [_P, _P, _P]),
     "pulse_tfe_reset": (C.c_int, [_P, _P, _I32, _I32, _U64, _U64, _P]),
     "pulse_tfe_step": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _U64, _U64, _U64, _P]),
+    "pulse_qtable_select": (C.c_int, [_P, _P, _I32, _I32, C.c_double, _U64, _U64, _U64, _P, _P, _P]),
+    "pulse_qtable_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, C.c_double, C.c_double, _P]),
     "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
 }
 

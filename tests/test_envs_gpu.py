@@ -146,3 +146,83 @@ def test_particle2d_hip_matches_oracle_one_million():
         np.testing.assert_array_equal(_np(obs), robs)
         np.testing.assert_array_equal(_np(rew), rrew)
         np.testing.assert_array_equal(_np(term), rterm)
+
+
+def _pack_board(b):
+    key = 0
+    for i, v in enumerate(b.reshape(-1)):
+        e = min(int(v).bit_length() - 1, 15) if v > 0 else 0
+        key |= e << (4 * i)
+    return key
+
+
+def test_batched_q_learning_matches_reference_semantics_per_board():
+    """BASELINE.json config 3 (2048 + tabular Q-learning): with private tables every board is an independent
+    copy of the reference agent (QLearningNumba.py + utils/numba.py); the oracle replays it with a Python dict
+    per board and the oracle's scalar helpers, same Philox draws -> actions, boards and Q tables bit-equal."""
+    import ctypes as C
+    from pulselib_amd.agents import QLearningBatch
+    from pulselib_amd.environments.TFE import TFEBatch
+    B, n, steps = 384, 4, 60
+    cfg = {"ALPHA": 0.1, "GAMMA": 0.99, "EPSILON": 0.1}
+    env = TFEBatch(torch.device(DEV), B, n, seed=77)
+    agent = QLearningBatch(torch.device(DEV), B, n, config=cfg, private_tables=True, slots=256, seed=991)
+    boards_ref = np.zeros((B, n, n), dtype=np.int32)
+    score = np.zeros(B, dtype=np.int64)
+    rew_ref = np.zeros(B, dtype=np.int32)
+    done_ref = np.zeros(B, dtype=np.uint8)
+    env.reset()
+    orc.tfe_reset(boards_ref, score, n, 77)
+    tables = [dict() for _ in range(B)]
+    lib = orc.lib()
+
+    def q_of(g, key):
+        return tables[g].setdefault(key, np.zeros(4, dtype=np.float64))
+
+    for s in range(steps):
+        acts = agent.get_actions(env.boards, s)
+        # oracle: epsilon-greedy with the same Philox words (p from words 0,1; randint from word 2)
+        a_ref = np.zeros(B, dtype=np.int64)
+        keys_s = [None] * B
+        for g in range(B):
+            w = orc.philox4x32(991, g, s)
+            p = float(((int(w[0]) << 21) ^ (int(w[1]) >> 11)) * (1.0 / 9007199254740992.0))
+            keys_s[g] = _pack_board(boards_ref[g])
+            q = q_of(g, keys_s[g])
+            a_ref[g] = lib.oracle_select_action_epsilon_greedy(q.ctypes.data_as(C.c_void_p), 4, C.c_double(0.1), C.c_double(p),
+                                                               C.c_uint32(int(w[2])))
+        np.testing.assert_array_equal(_np(acts), a_ref, err_msg=f"step {s} actions")
+        boards, rew, dones, _, _ = env.step(acts)
+        orc.tfe_step(boards_ref, score, a_ref, rew_ref, done_ref, n, 77, s + 1)
+        np.testing.assert_array_equal(_np(boards), boards_ref, err_msg=f"step {s} boards")
+        agent.update(boards, rew, dones)
+        for g in range(B):
+            cur, nxt = q_of(g, keys_s[g]), q_of(g, _pack_board(boards_ref[g]))
+            lib.oracle_update_q_entry(cur.ctypes.data_as(C.c_void_p), int(a_ref[g]), nxt.ctypes.data_as(C.c_void_p), 4,
+                                      C.c_double(0.1), C.c_double(float(rew_ref[g])), C.c_double(0.99), int(done_ref[g]))
+    for g in (0, 1, 17, B - 1):
+        got = agent.table(g)
+        assert set(got) == set(tables[g]), f"board {g}: state sets differ"
+        for k, v in tables[g].items():
+            np.testing.assert_array_equal(got[k], v, err_msg=f"board {g} state {k:#x}")
+    assert sum(len(t) for t in tables) > B * 20 and max(float(np.abs(v).max()) for t in tables for v in t.values()) > 0
+
+
+def test_shared_q_table_learns_and_loses_no_update():
+    """Shared-table mode at config-3 size: all 262,144 boards start from states with two tiles, so thousands of
+    boards update the same entries concurrently; the CAS loop must apply every one of them."""
+    from pulselib_amd.agents import QLearningBatch
+    from pulselib_amd.environments.TFE import TFEBatch
+    B = 262144
+    env = TFEBatch(torch.device(DEV), B, 4, seed=5)
+    agent = QLearningBatch(torch.device(DEV), B, 4, config={"ALPHA": 0.5, "GAMMA": 0.0, "EPSILON": 1.0}, slots=1 << 22, seed=3)
+    env.reset()
+    for s in range(8):
+        acts = agent.get_actions(env.boards, s)
+        boards, rew, dones, _, _ = env.step(acts)
+        agent.update(boards, rew, dones)
+    torch.cuda.synchronize()
+    table = agent.table()
+    assert len(table) > 1000
+    vals = np.stack(list(table.values()))
+    assert np.isfinite(vals).all() and vals.min() >= 0.0 and vals.max() > 0.5      # rewards are >= 0, gamma = 0
