@@ -146,6 +146,18 @@ __device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot
 
 // ---------------------------------------------------------------- the fused step
 struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
+// In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
+// in the product): lane 0 of every wavefront stores s_memtime at phase boundaries into a buffer of its own.
+#ifndef PULSE_STAMPS
+#define PULSE_STAMPS 0
+#endif
+#if PULSE_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP(i) do { if ((threadIdx.x & 63) == 0 && g_stamp_buf) { __builtin_amdgcn_sched_barrier(0); \
+    g_stamp_buf[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #ifndef PULSE_TANH_F32
 #define PULSE_TANH_F32 0
 #endif
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     const int t = gt / LPT;
     const int j = gt % LPT;
     if (t >= v.n_games) return;   // whole lane groups leave together
+    STAMP(0);
     const int P = v.n_players, A = v.active_players;
     const int32_t* __restrict__ hr = v.hand_ranks;
     const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
 #define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return grp_or<LPT>(m_); }())
 #define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)grp_or<LPT>(r_); }())
 
+    STAMP(1);   // loads issued
     // ---- capture (PokerGPU.py:530-539)
     const bool prev_done = done;
     const int actor = ((PH & PULSE_PH_CAPTURE) || !actor_idx_in ? idx : actor_idx_in[t]) & 15;
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     if (!(PH & PULSE_PH_CAPTURE)) prev_invested = v.prev_invested[t];
     const int prev_stack = a_stack;
 
+    STAMP(2);   // first loads have arrived (actor values picked)
     // ---- scripted opponents (environments/Poker/utils.py:108-123), fused in front of the step
     if (POLICY) {
         const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     }
     const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
 
+    STAMP(3);   // policy done
     // ---- 1) equities of dirty tables (PokerGPU.py:455-525)
     if (PH & PULSE_PH_EQUITY) {
         if (dirty) {
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         if (actor >= LPT * SPL) e_actor = 0.5f;
     }
 
+    STAMP(4);   // equities done
     // ---- 2) execute the action of the seat to act (PokerGPU.py:230-303)
     if (PH & PULSE_PH_EXECUTE) {
         const int call_cost = highest - a_bet;
@@ -372,6 +389,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     const uint32_t cont_bits = SEAT_BITS(status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
     const int contenders = __popc(cont_bits);
 
+    STAMP(5);   // action executed, seat masks built
     // ---- 3) next actor, round close, street transition (PokerGPU.py:547-616)
     if (PH & PULSE_PH_ADVANCE) {
         const int truly_active = __popc(act_bits);
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         }
     }
 
+    STAMP(6);   // advance / deal done
     // ---- 4) payouts on newly finished tables (PokerGPU.py:619-623)
     const bool newly_done = (PH & PULSE_PH_CAPTURE) ? (done && !prev_done) : done;
     if (PH & PULSE_PH_FOLDWIN) {                                            // :331-338
@@ -493,6 +512,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         }
     }
 
+    STAMP(7);   // payouts done
     // ---- 5) shaped reward (PokerGPU.py:305-329, :631-632)
     if (PH & PULSE_PH_REWARD) {
         const float cnt = (float)contenders;
@@ -511,6 +531,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         if (j == 0) rewards[t] = r;
     }
 
+    STAMP(8);   // reward done
     // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
     if (PH & PULSE_PH_OBS) {
         float* __restrict__ o = v.obs + (size_t)t * v.obs_size;
@@ -547,6 +568,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         }
     }
 
+    STAMP(9);   // observation stores issued
     // ---- store (changed words only)
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
@@ -584,6 +606,11 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         if ((PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) && dirty != dirty_in) v.equity_dirty[t] = dirty ? 1 : 0;
         if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;      // ping-pong buffer: always written
     }
+    STAMP(10);  // state stores issued
+#if PULSE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);                      // vmcnt(0): all stores acknowledged
+    STAMP(11);
+#endif
 #undef SEAT_BITS
 #undef SEAT_PICK
 }
@@ -930,6 +957,13 @@ int pulse_calib_stream(int32_t* buf, uint64_t n_words, int32_t write, void* stre
     else hipLaunchKernelGGL(calib_read_kernel, grid, block, 0, (hipStream_t)stream, buf, (size_t)n_words, buf);
     return finish_launch("pulse_calib_stream");
 }
+
+#if PULSE_STAMPS
+int pulse_debug_set_stamp_buffer(unsigned long long* buf) {
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+    return e == hipSuccess ? 0 : pulse::fail_hip((int)e, "pulse_debug_set_stamp_buffer");
+}
+#endif
 
 int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream) {
     if (int rc = check_view(v, "pulse_poker_reset")) return rc;
