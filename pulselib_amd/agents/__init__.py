@@ -1,3 +1,4 @@
+from .first_visit_mc import FirstVisitMonteCarlo
 from .qlearning import QLearningBatch
 
-__all__ = ["QLearningBatch"]
+__all__ = ["FirstVisitMonteCarlo", "QLearningBatch"]

@@ -358,13 +358,17 @@ class PokerGPU(_EnvBase):
     # ------------------------------------------------------------------ white-box methods
     def _phases(self, phases, actions=None, actor_idx=None, rewards=None):
         v = self._view(inplace=True)
-        a = self._actions(actions).data_ptr() if actions is not None else None
-        ai = None
+        # converted copies must stay referenced until the launch is enqueued (the caching allocator would
+        # otherwise hand their memory to the next conversion)
+        act_t = self._actions(actions) if actions is not None else None
+        idx_t = None
         if actor_idx is not None:
-            actor_idx = torch.as_tensor(actor_idx).to(device=self.device, dtype=torch.int32).contiguous()
-            ai = actor_idx.data_ptr()
-        r = rewards.data_ptr() if rewards is not None else None
-        _native.check(self._lib.pulse_poker_phases(C.byref(v), phases, a, ai, r, self._stream()), "pulse_poker_phases")
+            idx_t = torch.as_tensor(actor_idx).to(device=self.device, dtype=torch.int32).contiguous()
+        _native.check(self._lib.pulse_poker_phases(C.byref(v), phases, act_t.data_ptr() if act_t is not None else None,
+                                                   idx_t.data_ptr() if idx_t is not None else None,
+                                                   rewards.data_ptr() if rewards is not None else None, self._stream()),
+                      "pulse_poker_phases")
+        del act_t, idx_t
 
     def get_obs(self):                               # PokerGPU.py:159-179
         self._phases(_native.PH_OBS)

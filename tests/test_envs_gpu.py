@@ -226,3 +226,15 @@ def test_shared_q_table_learns_and_loses_no_update():
     assert len(table) > 1000
     vals = np.stack(list(table.values()))
     assert np.isfinite(vals).all() and vals.min() >= 0.0 and vals.max() > 0.5      # rewards are >= 0, gamma = 0
+
+
+def test_blackjack_first_visit_mc_plumbing():
+    """BASELINE.json config 1: GPU blackjack batches -> CPU first-visit MC.  Sanity of the estimates under the
+    'hit below 17' policy: standing on 20/21 is clearly good, every value lies in [-1, 1]."""
+    from pulselib_amd.scripts.blackjack_fvmc import run
+    agent, n = run(torch.device(DEV), batches=3, batch_size=1000, gamma=0.9, seed=7)
+    assert n == 3000 and len(agent.values) > 50
+    assert all(-1.0 <= v <= 1.0 for v in agent.values.values())
+    strong = [v for (s, ace, up), v in agent.values.items() if s in (20, 21)]
+    weak = [v for (s, ace, up), v in agent.values.items() if s in (14, 15, 16) and not ace]
+    assert sum(strong) / len(strong) > 0.5 > sum(weak) / len(weak)

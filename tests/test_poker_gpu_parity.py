@@ -327,3 +327,106 @@ def test_sharding_is_invisible_to_the_games():
         for name in INT_KEYS + ("decks", "obs", "equities"):
             got = np.concatenate([to_np(getattr(p, name)) for p in parts])
             np.testing.assert_array_equal(got, to_np(getattr(whole, name)), err_msg=name)
+
+
+# ---- white-box helper contracts (data restated from the reference's tests/poker/test_poker_gpu_state_contracts.py
+#      :69-127 and test_poker_gpu_reward_equity_contracts.py:26-110) ------------------------------------------
+def _fresh(n_players, n_games=1):
+    env = _gpu_env(n_players=n_players, max_players=n_players, n_games=n_games)
+    env.reset(options={"active_players": False, "q_agent_seat": 0, "rotation": 0})
+    env.active_players = n_players
+    return env
+
+
+def test_post_blinds_updates_pot_bets_and_allin_status():
+    env = _fresh(2, 2)
+    env.pots.zero_(); env.current_round_bet.zero_(); env.total_invested.zero_()
+    env.status.fill_(env.ACTIVE); env.stacks.zero_()
+    env.bb = torch.tensor([0, 1], dtype=torch.int32)            # CPU tensor, as the reference test passes it
+    env.stacks[0, 0] = 1
+    env.stacks[1, 1] = 5
+    env.post_blinds()
+    assert env.pots.tolist() == [1, 1]
+    assert env.current_round_bet.tolist() == [[1, 0], [0, 1]]
+    assert env.total_invested.tolist() == [[1, 0], [0, 1]]
+    assert env.stacks.tolist() == [[0, 0], [0, 4]]
+    assert env.status.tolist() == [[env.ALLIN, env.ACTIVE], [env.ACTIVE, env.ACTIVE]]
+
+
+def test_deal_helpers_and_get_info():
+    env = _fresh(2, 2)
+    env.decks[0] = torch.arange(1, 53, dtype=torch.int32)
+    env.decks[1] = torch.arange(101, 153, dtype=torch.int32)
+    env.deck_positions.zero_()
+    assert env.deal_players_cards(4).tolist() == [[1, 2, 3, 4], [101, 102, 103, 104]]
+    assert env.deal_players_cards(2).tolist() == [[5, 6], [105, 106]]
+    assert env.deck_positions.tolist() == [6, 6]
+    env.deck_positions[:] = torch.tensor([5, 7], dtype=torch.int32)
+    cards = env.deal_cards(torch.tensor([1], dtype=torch.long, device=DEV), 2)
+    assert cards.tolist() == [[108, 109]] and cards.dtype == torch.int32
+    assert env.deck_positions.tolist() == [5, 9]
+    env3 = _fresh(3)
+    env3.active_players = 2
+    env3.idx[0] = 1
+    env3.stacks[0] = torch.tensor([40, 50, 60], dtype=torch.int32)
+    info = env3.get_info()
+    assert info["active_players"] == 2 and torch.equal(info["seat_idx"], env3.idx) and torch.equal(info["stacks"], env3.stacks)
+
+
+def test_obs_packing_relative_order_and_padding():
+    """test_poker_gpu_environment_logic_matrix.py:165-177 / state_contracts: opponents in seat order after the actor."""
+    env = _gpu_env(n_players=4, max_players=6, n_games=1)
+    env.reset(options={"active_players": False})
+    env.idx[0] = 1
+    env.stacks[0] = torch.tensor([101, 102, 103, 104], dtype=torch.int32)
+    env.status[0] = torch.tensor([env.ACTIVE, env.FOLDED, env.ALLIN, env.ACTIVE], dtype=torch.int32)
+    env.current_round_bet[0] = torch.tensor([11, 12, 13, 14], dtype=torch.int32)
+    obs = env.get_obs()
+    assert obs.shape == (1, 13 + 3 * 5)
+    assert obs[0, 11].item() == 102 and obs[0, 12].item() == env.FOLDED
+    assert obs[0, 13:22].to(torch.int32).tolist() == [103, env.ALLIN, 13, 104, env.ACTIVE, 14, 101, env.ACTIVE, 11]
+    assert obs[0, 22:].tolist() == [0.0] * 6
+
+
+def test_poker_reward_gpu_contracts_and_oracle(oracle_table):
+    env = _fresh(3, 3)
+    env.status[:] = env.ACTIVE
+    env.pots.zero_(); env.highest.zero_(); env.prev_invested.zero_()
+    env.equities[:] = 0.5
+    r = env.poker_reward_gpu(actions=torch.tensor([0, 1, 12], dtype=torch.long), actor_idx=torch.tensor([0, 0, 0], dtype=torch.int32))
+    assert torch.isfinite(r).all() and r.abs().max().item() < 1e-6
+
+    env = _fresh(2, 2)
+    env.status[:] = env.ACTIVE
+    env.pots[:] = 20; env.highest[:] = 10; env.prev_invested[:] = 0
+    env.equities[0] = torch.tensor([0.2, 0.8]); env.equities[1] = torch.tensor([0.8, 0.2])
+    r = env.poker_reward_gpu(actions=torch.tensor([1, 1]), actor_idx=torch.tensor([0, 0], dtype=torch.int32))
+    assert r[1].item() > r[0].item()                                   # call reward grows with equity
+    env.w1 = torch.tensor(0.0, device=env.device); env.w2 = torch.tensor(1.0, device=env.device)
+    r = env.poker_reward_gpu(actions=torch.tensor([0, 0]), actor_idx=torch.tensor([0, 0], dtype=torch.int32))
+    assert r[1].item() < r[0].item()                                   # fold reward falls with equity
+
+    # random states against the oracle's restatement of PokerGPU.py:305-329
+    from oracle import oracle as orc
+    import ctypes as C
+    N, P = 512, 6
+    env = _gpu_env(n_players=P, max_players=10, n_games=N, w1=.7, w2=.2, K=37, alpha=11)
+    ref = orc.OraclePokerEnv(n_players=P, max_players=10, n_games=N, w1=.7, w2=.2, K=37, alpha=11, hand_ranks_table=oracle_table)
+    decks = _seeded_decks(N, 5)
+    env.reset(options={"prefixed_decks": decks}); ref.reset(options={"prefixed_decks": decks.numpy()})
+    rng = np.random.default_rng(9)
+    status = rng.integers(0, 3, (N, P)).astype(np.int32)
+    pots = rng.integers(0, 500, N).astype(np.int32)
+    highest = rng.integers(0, 80, N).astype(np.int32)
+    prev_inv = rng.integers(0, 80, N).astype(np.int32)
+    eqs = rng.random((N, P)).astype(np.float32)
+    acts = rng.integers(-1, 14, N).astype(np.int64)
+    actor = rng.integers(0, P, N).astype(np.int32)
+    for e, vals in ((env, lambda x: torch.from_numpy(x).to(DEV)), (ref, lambda x: x)):
+        e.status[...] = vals(status); e.pots[...] = vals(pots); e.highest[...] = vals(highest)
+        e.prev_invested[...] = vals(prev_inv); e.equities[...] = vals(eqs)
+    got = to_np(env.poker_reward_gpu(torch.from_numpy(acts), torch.from_numpy(actor)))
+    s = ref._struct()
+    want = np.array([orc.lib().oracle_reward(C.byref(s), C.c_int(t), C.c_int64(int(acts[t])), C.c_int(int(actor[t]))) for t in range(N)],
+                    dtype=np.float32)
+    np.testing.assert_allclose(got, want, rtol=0, atol=reward_tol(11))
