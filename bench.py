@@ -171,9 +171,16 @@ class Runner:
         if self.world > 1:
             import torch.distributed as dist
             # the only cross-GPU exchange of the path: episode statistics (RCCL all-reduce over xGMI)
+            if getattr(self, "_stats_work", None) is not None:
+                self._stats_work.wait()              # stream-ordered for RCCL: the buffer is about to be rewritten
+                self._stats_work = None
             self.episode_stats[0] = self.env.is_done.sum()
             self.episode_stats[1] = self.env._rewards[0].sum()
-            dist.all_reduce(self.episode_stats, async_op=True)
+            if dist.get_backend() == "gloo":      # one-GPU rehearsal: gloo reduces host copies
+                host = self.episode_stats.cpu()
+                dist.all_reduce(host)
+            else:
+                self._stats_work = dist.all_reduce(self.episode_stats, async_op=True)
         self.new_episode()
 
 
@@ -240,12 +247,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal knob for a one-GPU box: PULSE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 with the gloo
+    # backend (RCCL refuses two ranks on one GPU); the driver's real runs use one GPU per rank over RCCL
+    one_device = os.environ.get("PULSE_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     def barrier():
         if world > 1:
@@ -275,7 +290,7 @@ def main():
     lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

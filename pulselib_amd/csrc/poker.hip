@@ -145,7 +145,7 @@ __device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot
 }
 
 // ---------------------------------------------------------------- the fused step
-struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
+struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; int stagger; };
 // In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
 // in the product): lane 0 of every wavefront stores s_memtime at phase boundaries into a buffer of its own.
 #ifndef PULSE_STAMPS
@@ -160,6 +160,9 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #endif
 #ifndef PULSE_TANH_F32
 #define PULSE_TANH_F32 0
+#endif
+#ifndef PULSE_KERNARG_EARLY
+#define PULSE_KERNARG_EARLY 1
 #endif
 #ifndef PULSE_PREFETCH_DECK
 #define PULSE_PREFETCH_DECK 0
@@ -222,16 +225,35 @@ __device__ __forceinline__ float tanh_rn(float x) {
 #endif
 }
 
-template <uint32_t PH, bool POLICY, int LPT, int SPL>
+// WOBS (LPT = 4, n_games % 16 == 0): the observation rows of a wavefront's 16 tables are one contiguous
+// 16 x obs_size x 4 B block in HBM.  Written column by column they cost thirteen store instructions that each
+// touch sixteen cache lines; with WOBS the lanes drop their values into the wavefront's LDS slice and the
+// block leaves as three 1-KiB bursts (16 B per lane).  A wavefront's LDS operations retire in order, so no
+// workgroup barrier is involved.
+template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS>
 __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
                                                            const int32_t* __restrict__ actor_idx_in,
                                                            float* __restrict__ rewards, const PolicyArgs pa) {
     static_assert(LPT * SPL >= 1 && LPT * SPL <= 16 * 16 && (LPT & (LPT - 1)) == 0, "bad table mapping");
+    static_assert(!WOBS || LPT == 4, "observation staging is written for 4 lanes per table");
+    extern __shared__ int4 smem4[];
     const int gt = blockIdx.x * kBlock + threadIdx.x;
     const int t = gt / LPT;
     const int j = gt % LPT;
+#if PULSE_KERNARG_EARLY
+    // Fetch the whole argument block before the first wait: left alone, the compiler sinks the scalar loads
+    // of the ~40 view pointers next to their uses and the prologue pays five dependent scalar-cache trips.
+    asm volatile("" :: "s"(v.pots), "s"(v.stages), "s"(v.deck_positions), "s"(v.button), "s"(v.idx), "s"(v.highest), "s"(v.agg),
+                 "s"(v.acted), "s"(v.last_raise_size), "s"(v.is_done), "s"(v.equity_dirty), "s"(v.board));
+    asm volatile("" :: "s"(v.stacks), "s"(v.current_round_bet), "s"(v.total_invested), "s"(v.status), "s"(v.hands), "s"(v.equities),
+                 "s"(v.pre_board), "s"(v.w1), "s"(v.w2), "s"(v.K), "s"(v.alpha), "s"(actions));
+#endif
     if (t >= v.n_games) return;   // whole lane groups leave together
     STAMP(0);
+    if (pa.stagger > 0) {          // experiment: delay part of the workgroups so load and compute phases of different groups overlap
+        const int ph = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < pa.stagger * ph; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     const int P = v.n_players, A = v.active_players;
     const int32_t* __restrict__ hr = v.hand_ranks;
     const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
@@ -534,7 +556,9 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     STAMP(8);   // reward done
     // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
     if (PH & PULSE_PH_OBS) {
-        float* __restrict__ o = v.obs + (size_t)t * v.obs_size;
+        const int wlane = threadIdx.x & 63;
+        float* const l_obs = reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * 16 * v.obs_size;
+        float* __restrict__ o = WOBS ? l_obs + (wlane >> 2) * v.obs_size : v.obs + (size_t)t * v.obs_size;
         const int seat_i = idx & 15;
         const int n_h0 = SEAT_PICK(h0, seat_i), n_h1 = SEAT_PICK(h1, seat_i);
         const int n_stack = SEAT_PICK(stack, seat_i), n_status = SEAT_PICK(status, seat_i), n_bet = SEAT_PICK(bet, seat_i);
@@ -568,42 +592,56 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         }
     }
 
+    if (WOBS && (PH & PULSE_PH_OBS)) {
+        const int wlane = threadIdx.x & 63;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n4 = 4 * v.obs_size;                                   // int4 per wavefront block
+        const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) << 4;   // first table of this wavefront
+        int4* dst = reinterpret_cast<int4*>(v.obs + (size_t)tw0 * v.obs_size);
+        const int4* src = reinterpret_cast<const int4*>(smem4) + (threadIdx.x >> 6) * n4;
+        for (int e = wlane; e < n4; e += 64) dst[e] = src[e];
+    }
     STAMP(9);   // observation stores issued
-    // ---- store (changed words only)
+    // ---- store (changed records only: a seat's four cells and the per-table scalars change together, so
+    //      one test per seat / per table guards each group of stores instead of one branch per word)
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int seat = j + LPT * k;
-        if (seat < P) {
-            if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) && stack[k] != stack_in[k]) v.stacks[row0 + seat] = stack[k];
-            if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) && bet[k] != bet_in[k]) v.current_round_bet[row0 + seat] = bet[k];
-            if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) && inv[k] != inv_in[k]) v.total_invested[row0 + seat] = inv[k];
-            if ((PH & PULSE_PH_EXECUTE) && status[k] != status_in[k]) v.status[row0 + seat] = status[k];
+        const bool changed = (stack[k] != stack_in[k]) | (bet[k] != bet_in[k]) | (inv[k] != inv_in[k]) | (status[k] != status_in[k]);
+        if (seat < P && changed) {
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.stacks[row0 + seat] = stack[k];
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.current_round_bet[row0 + seat] = bet[k];
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) v.total_invested[row0 + seat] = inv[k];
+            if (PH & PULSE_PH_EXECUTE) v.status[row0 + seat] = status[k];
         }
     }
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
+        const bool board_changed = (b0 != b0_in) | (b1 != b1_in) | (b2 != b2_in) | (b3 != b3_in) | (b4 != b4_in);
+        if (board_changed) {
 #pragma unroll
-        for (int c0 = 0; c0 < 5; c0 += LPT) {
-            const int c = c0 + j;
-            const int bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4;
-            const int bi = c == 0 ? b0_in : c == 1 ? b1_in : c == 2 ? b2_in : c == 3 ? b3_in : b4_in;
-            if (c < 5 && bv != bi) v.board[t * 5 + c] = bv;
+            for (int c0 = 0; c0 < 5; c0 += LPT) {
+                const int c = c0 + j;
+                if (c < 5) v.board[t * 5 + c] = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4;
+            }
         }
     }
     if (j == 0) {
         if (PH & PULSE_PH_CAPTURE) { v.prev_stacks[t] = prev_stack; v.prev_invested[t] = prev_invested; }
-        if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) && pot != pot_in) v.pots[t] = pot;
-        if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) && highest != highest_in) v.highest[t] = highest;
-        if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) {
-            if (agg != agg_in) v.agg[t] = agg;
-            if (acted != acted_in) v.acted[t] = acted;
-            if (lrs != lrs_in) v.last_raise_size[t] = lrs;
+        const bool betting_changed = (pot != pot_in) | (highest != highest_in) | (agg != agg_in) | (acted != acted_in) |
+                                     (lrs != lrs_in) | (idx != idx_in);
+        if (betting_changed) {
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.pots[t] = pot;
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.highest[t] = highest;
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { v.agg[t] = agg; v.acted[t] = acted; v.last_raise_size[t] = lrs; }
+            if (PH & PULSE_PH_ADVANCE) v.idx[t] = idx;
         }
-        if ((PH & PULSE_PH_ADVANCE) && idx != idx_in) v.idx[t] = idx;
-        if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
-            if (stage != stage_in) v.stages[t] = stage;
-            if (dpos != dpos_in) v.deck_positions[t] = dpos;
+        const bool street_changed = (stage != stage_in) | (dpos != dpos_in) | (dirty != dirty_in);
+        if (street_changed) {
+            if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { v.stages[t] = stage; v.deck_positions[t] = dpos; }
+            if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) v.equity_dirty[t] = dirty ? 1 : 0;
         }
-        if ((PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) && dirty != dirty_in) v.equity_dirty[t] = dirty ? 1 : 0;
         if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;      // ping-pong buffer: always written
     }
     STAMP(10);  // state stores issued
@@ -851,10 +889,21 @@ int lanes_per_table() {
     return g_lpt;
 }
 
+int g_stagger = -1;
+int stagger_knob() {
+    if (g_stagger < 0) { const char* e = getenv("PULSE_STAGGER"); g_stagger = e ? atoi(e) : 0; }
+    return g_stagger;
+}
 int g_lds_pad = -1;
 int lds_pad() {      // experiment knob: dynamic LDS bytes per workgroup, only to cap workgroups per CU
     if (g_lds_pad < 0) { const char* e = getenv("PULSE_LDS_PAD"); g_lds_pad = e ? atoi(e) : 0; }
     return g_lds_pad;
+}
+
+int g_wobs = -1;
+bool obs_staging_enabled() {
+    if (g_wobs < 0) { const char* e = getenv("PULSE_WOBS"); g_wobs = (e && atoi(e) == 0) ? 0 : 1; }
+    return g_wobs != 0;
 }
 
 template <uint32_t PH, bool POLICY>
@@ -864,17 +913,22 @@ void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor
     const dim3 grid((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)), block(kBlock);
     const int pad = lds_pad();
     const int spl = (v.max_players + lpt - 1) / lpt;   // seats per lane needed to cover max_players (obs padding too)
-    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (PH == PULSE_PH_STEP && obs_staging_enabled() && (v.n_games & 15) == 0 && ((uintptr_t)v.obs & 15u) == 0) {
+        const size_t lds = sizeof(float) * (size_t)(kBlock / 64) * 16 * (size_t)v.obs_size;
+        if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3, PH == PULSE_PH_STEP>), grid, block, lds, st, v, actions, actor_idx, rewards, pa);
+        else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4, PH == PULSE_PH_STEP>), grid, block, lds, st, v, actions, actor_idx, rewards, pa);
+    }
+    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
 }
 
 template <uint32_t PH>
 void launch_phase(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, hipStream_t st) {
-    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0}, st);
+    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0, 0}, st);
 }
 
 }  // namespace
@@ -894,7 +948,7 @@ int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types,
     if (int rc = check_view(v, "pulse_poker_policy_step")) return rc;
     if (!actions || !rewards || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_policy_step: null argument");
     if (v->n_games == 0) return 0;
-    const PolicyArgs pa{pack_types(agent_types, v->n_players), seed, step_counter, table_id0};
+    const PolicyArgs pa{pack_types(agent_types, v->n_players), seed, step_counter, table_id0, stagger_knob()};
     launch_step<PULSE_PH_STEP, true>(*v, actions, nullptr, rewards, pa, (hipStream_t)stream);
     return finish_launch("pulse_poker_policy_step");
 }
@@ -931,9 +985,9 @@ int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* action
                        uint64_t step_counter, void* stream) {
     if (int rc = check_view(v, "pulse_poker_ablate")) return rc;
     const dim3 grid((unsigned)(((long long)v->n_games * 4 + kBlock - 1) / kBlock)), block(kBlock);
-    const PolicyArgs pa{types_packed, 1, step_counter, 0};
+    const PolicyArgs pa{types_packed, 1, step_counter, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-#define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 4, 3>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa); break;
+#define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 4, 3, false>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa); break;
     switch (phases) {
     PULSE_ABL(PULSE_PH_STEP)
     PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_EQUITY)
@@ -1028,7 +1082,7 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     for (int i = 0; i < n_steps; ++i) {
         const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
         float* rw = (i & 1) ? rewards_odd : rewards_even;
-        const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0};
+        const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0, stagger_knob()};
         launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
     }
     if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); g_ev_launches[g_ev_used] = n_steps; ++g_ev_used; }
