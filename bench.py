@@ -241,6 +241,9 @@ def recorded_traffic(tables):
 
 
 def main():
+    import faulthandler
+    # a bench that takes minutes is a bug: dump every thread's stack and exit instead of hanging the box
+    faulthandler.dump_traceback_later(int(os.environ.get("PULSE_BENCH_WATCHDOG_S", "360")), exit=True)
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
