@@ -281,6 +281,9 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     }
     long long act64 = 0;
     if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = actions[t];
+    // the Philox draw of this (table, step) depends on no load: issue it now, it executes under the load latency
+    U4 rnd{0, 0, 0, 0};
+    if (POLICY) rnd = philox4x32(pa.seed, pa.table_id0 + (uint64_t)t, pa.step_counter);
     const float w1 = *v.w1, w2 = *v.w2;
     const int Kdiv = *v.K, alpha = *v.alpha;
     uint32_t pre_tag = 0;
@@ -323,7 +326,6 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     if (POLICY) {
         const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
         if (type != PULSE_AGENT_EXTERNAL) {
-            const U4 rnd = philox4x32(pa.seed, pa.table_id0 + (uint64_t)t, pa.step_counter);
             const int seat_i = idx & 15;
             act64 = scripted_action(type, SEAT_PICK(h0, seat_i), SEAT_PICK(h1, seat_i), pot, rnd);
             if (j == 0) actions[t] = act64;
