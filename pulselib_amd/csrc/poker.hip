@@ -566,18 +566,27 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         const int n_stack = SEAT_PICK(stack, seat_i), n_status = SEAT_PICK(status, seat_i), n_bet = SEAT_PICK(bet, seat_i);
         const int idxm = mod_near(idx, A);
         const int pos = mod_near(idx - button, A);
+        if (LPT == 4) {
+            // columns 0..12, four per lane-quad pass: lane j writes column 4*pass + j (a 4-way select per pass)
+            const int h0v = j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
+            const int h1v = j == 0 ? b4 : j == 1 ? n_h0 : j == 2 ? n_h1 : stage;
+            const int h2v = j == 0 ? pos : j == 1 ? pot : j == 2 ? highest - n_bet : n_stack;
+            o[j] = (float)h0v; o[4 + j] = (float)h1v; o[8 + j] = (float)h2v;
+            if (j == 0) o[12] = (float)n_status;
+        } else {
 #pragma unroll
-        for (int c0 = 0; c0 < 13; c0 += LPT) {
-            const int c = c0 + j;
-            if (c < 13) {
-                int hv;
-                switch (c) {
-                case 0: hv = b0; break; case 1: hv = b1; break; case 2: hv = b2; break; case 3: hv = b3; break;
-                case 4: hv = b4; break; case 5: hv = n_h0; break; case 6: hv = n_h1; break; case 7: hv = stage; break;
-                case 8: hv = pos; break; case 9: hv = pot; break; case 10: hv = highest - n_bet; break;
-                case 11: hv = n_stack; break; default: hv = n_status; break;
+            for (int c0 = 0; c0 < 13; c0 += LPT) {
+                const int c = c0 + j;
+                if (c < 13) {
+                    int hv;
+                    switch (c) {
+                    case 0: hv = b0; break; case 1: hv = b1; break; case 2: hv = b2; break; case 3: hv = b3; break;
+                    case 4: hv = b4; break; case 5: hv = n_h0; break; case 6: hv = n_h1; break; case 7: hv = stage; break;
+                    case 8: hv = pos; break; case 9: hv = pot; break; case 10: hv = highest - n_bet; break;
+                    case 11: hv = n_stack; break; default: hv = n_status; break;
+                    }
+                    o[c] = (float)hv;
                 }
-                o[c] = (float)hv;
             }
         }
         // opponents: seat (idx+1+k)%A -> columns 13+3k..; seats >= A zero-fill the padding slots
