@@ -1,33 +1,36 @@
-"""First-visit Monte-Carlo state-value estimator: same interface and arithmetic as the reference's
-agents/MonteCarlo/FirstVisitMonteCarlo.py:5-31 (CPU, pure Python -- BASELINE.json config 1 is CPU plumbing).
-`learn(episode)` takes [(state, action, reward), ...]; for the first visit of each state the discounted
-return from that time step is added to the running mean."""
+"""First-visit Monte-Carlo state-value estimation on the CPU (BASELINE.json config 1 is CPU plumbing).
+
+Interface and arithmetic of the reference's agents/MonteCarlo/FirstVisitMonteCarlo.py:5-31: `learn` takes one
+episode as [(state, action, reward), ...]; the discounted return G_t = r_t + gamma * G_{t+1} is accumulated from
+the end of the episode, and for the FIRST occurrence of each state its G_t updates that state's running mean
+(`returns[state] = [sum, count]`, `values[state] = sum / count`)."""
 from __future__ import annotations
 
 from collections import defaultdict
-from typing import Dict, List, Tuple
 
 
 class FirstVisitMonteCarlo:
     def __init__(self, gamma: float):
-        self.values: Dict[Tuple, float] = defaultdict(float)
-        self.returns: Dict[Tuple, List[float]] = defaultdict(lambda: [0.0, 0.0])   # [sum of returns, count]
         self.gamma = gamma
+        self.values = defaultdict(float)                     # state -> mean first-visit return
+        self.returns = defaultdict(lambda: [0.0, 0.0])       # state -> [sum of returns, number of episodes]
 
     def action(self, action_space):
         return action_space.sample()
 
-    def learn(self, episode: List[tuple]):
-        first_visit = {}
-        for t, (state, _, _) in enumerate(episode):
-            if state not in first_visit:
-                first_visit[state] = t
-        g = 0
-        for i in range(len(episode) - 1, -1, -1):                       # FirstVisitMonteCarlo.py:24-31
-            state, _, reward = episode[i]
-            g = self.gamma * g + reward
-            if first_visit[state] == i:
-                r = self.returns[state]
-                r[0] += g
-                r[1] += 1
-                self.values[state] = r[0] / r[1]
+    def learn(self, episode):
+        # discounted return of every time step, computed backwards
+        tail, discounted = 0, [0.0] * len(episode)
+        for t in reversed(range(len(episode))):
+            tail = self.gamma * tail + episode[t][2]
+            discounted[t] = tail
+        # the earliest time step of each state; the reference applies the updates walking backwards
+        # (FirstVisitMonteCarlo.py:24-31), which only matters for the insertion order of new states
+        first_seen = {}
+        for t, step in enumerate(episode):
+            first_seen.setdefault(step[0], t)
+        for state, t in sorted(first_seen.items(), key=lambda kv: -kv[1]):
+            total = self.returns[state]
+            total[0] += discounted[t]
+            total[1] += 1
+            self.values[state] = total[0] / total[1]

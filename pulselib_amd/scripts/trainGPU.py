@@ -128,15 +128,17 @@ def main():
     import yaml
     from ..environments.Poker import PokerGPU, load_gpu_agents
     cfg = yaml.safe_load((Path(__file__).resolve().parent.parent / "config" / "pokerGPU.yaml").read_text())
+    env_cfg, rew, learner = cfg["env"], cfg["reward"], cfg["learner"]
     device = torch.device("cuda", torch.cuda.current_device())
-    n_games = int(cfg["N_GAMES"])
-    agents, types = load_gpu_agents(device, cfg["NUM_PLAYERS"], cfg["AGENTS"], cfg["STARTING_BBS"], cfg["ACTION_SPACE"])
-    agents.insert(0, SimpleQNetwork(device, gamma=cfg["GAMMA"], state_dim=cfg["STATE_SPACE"], lr=float(cfg["LEARNING_RATE"])))
+    n_games = int(env_cfg["tables"])
+    agents, types = load_gpu_agents(device, env_cfg["opponents"], list(cfg["opponent_mix"]), env_cfg["starting_stack_bb"], env_cfg["actions"])
+    agents.insert(0, SimpleQNetwork(device, gamma=learner["gamma"], state_dim=env_cfg["observation_size"], lr=float(learner["learning_rate"])))
     types.insert(0, PokerAgentType.QLEARNING)
-    env = PokerGPU(device=device, agents=agents, n_players=cfg["NUM_PLAYERS"] + 1, n_games=n_games, starting_bbs=cfg["STARTING_BBS"],
-                   w1=cfg["W1"], w2=cfg["W2"], K=cfg["K"], alpha=cfg["ALPHA"], seed=cfg.get("SEED", 0))
-    out = train_agent(env, agents, types, int(cfg["EPISODES"]), n_games, device, config=cfg,
-                      max_episode_steps=cfg.get("MAX_EPISODE_STEPS"))
+    env = PokerGPU(device=device, agents=agents, n_players=env_cfg["opponents"] + 1, n_games=n_games,
+                   starting_bbs=env_cfg["starting_stack_bb"], w1=rew["w1"], w2=rew["w2"], K=rew["K"], alpha=rew["alpha"],
+                   seed=env_cfg.get("seed", 0))
+    out = train_agent(env, agents, types, int(cfg["run"]["episodes"]), n_games, device, config={"ENV_ID": env_cfg["id"], **cfg["run"]},
+                      max_episode_steps=env_cfg.get("max_episode_steps"))
     print({k: out[k] for k in ("total_steps", "total_training_seconds", "sps")})
 
 
