@@ -240,6 +240,11 @@ def recorded_traffic(tables):
     return best
 
 
+def _log(msg):
+    """Progress marks on stderr (stdout carries only the JSON line): a silent bench cannot be told from a hung one."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     import faulthandler
     # a bench that takes minutes is a bug: dump every thread's stack and exit instead of hanging the box
@@ -272,12 +277,18 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        _log("cpu_baseline (oracle port) ...")
         cpu = cpu_baseline(args, args.tables)
+        _log(f"cpu_baseline done: {cpu['value']:.3g} steps/s on {cpu['cores']} cores")
 
     runner = Runner(args, rank, world, device)
     lib = runner.env._lib
+    if rank == 0:
+        _log(f"environment ready ({args.tables} tables/GPU x {world}); warm-up {args.warmup} steps ...")
     runner.run_steps(args.warmup)
     torch.cuda.synchronize()
+    if rank == 0:
+        _log(f"timing {args.steps} steps ...")
     s_ms, n_t = C.c_float(0), C.c_int32(0)
     lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))     # drop warm-up samples
 
@@ -289,6 +300,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert ran == args.steps
+    if rank == 0:
+        _log(f"timed region done: {elapsed * 1e3:.1f} ms")
 
     lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))
     if world > 1:
