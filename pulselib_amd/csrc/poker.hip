@@ -144,8 +144,17 @@ __device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot
     return a;
 }
 
+// 32-bit byte-offset addressing: base pointers are wave-uniform (SGPR pair) and every array of a view is
+// far below 4 GiB, so an access is `global_load v, v_off, s[base]` with no 64-bit VALU address arithmetic.
+template <class T> __device__ __forceinline__ T ldo(const T* __restrict__ base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T> __device__ __forceinline__ void sto(T* __restrict__ base, uint32_t byte_off, T val) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = val;
+}
+
 // ---------------------------------------------------------------- the fused step
-struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; int stagger; };
+struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
 // In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
 // in the product): lane 0 of every wavefront stores s_memtime at phase boundaries into a buffer of its own.
 #ifndef PULSE_STAMPS
@@ -250,44 +259,42 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
 #endif
     if (t >= v.n_games) return;   // whole lane groups leave together
     STAMP(0);
-    if (pa.stagger > 0) {          // experiment: delay part of the workgroups so load and compute phases of different groups overlap
-        const int ph = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < pa.stagger * ph; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     const int P = v.n_players, A = v.active_players;
     const int32_t* __restrict__ hr = v.hand_ranks;
     const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
-    const size_t row0 = (size_t)t * P;
 
     // ---- load (every load is independent: all in flight at once)
-    int idx = v.idx[t], button = v.button[t], pot = v.pots[t], stage = v.stages[t], dpos = v.deck_positions[t];
-    int highest = v.highest[t], agg = v.agg[t], acted = v.acted[t], lrs = v.last_raise_size[t];
-    bool done = v.is_done[t] != 0;
-    bool dirty = v.equity_dirty[t] != 0;
-    int b0 = v.board[t * 5 + 0], b1 = v.board[t * 5 + 1], b2 = v.board[t * 5 + 2], b3 = v.board[t * 5 + 3], b4 = v.board[t * 5 + 4];
+    const uint32_t ut = (uint32_t)t, so = ut * 4u, bo = ut * 20u;      // byte offsets into [N] int32 / board
+    int idx = ldo(v.idx, so), button = ldo(v.button, so), pot = ldo(v.pots, so), stage = ldo(v.stages, so), dpos = ldo(v.deck_positions, so);
+    int highest = ldo(v.highest, so), agg = ldo(v.agg, so), acted = ldo(v.acted, so), lrs = ldo(v.last_raise_size, so);
+    bool done = ldo(v.is_done, ut) != 0;
+    bool dirty = ldo(v.equity_dirty, ut) != 0;
+    int b0 = ldo(v.board, bo), b1 = ldo(v.board, bo + 4), b2 = ldo(v.board, bo + 8), b3 = ldo(v.board, bo + 12), b4 = ldo(v.board, bo + 16);
     int stack[SPL], bet[SPL], inv[SPL], status[SPL], h0[SPL], h1[SPL];
     float eq[SPL];
+    uint32_t ro[SPL];                                                  // byte offset of (table, seat) in an [N,P] int32 array
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int seat = j + LPT * k;
+        ro[k] = (ut * (uint32_t)P + (uint32_t)seat) * 4u;
         stack[k] = 0; bet[k] = 0; inv[k] = 0; status[k] = PULSE_SITOUT; h0[k] = -1; h1[k] = -1; eq[k] = 0.5f;
         if (seat < P) {
-            stack[k] = v.stacks[row0 + seat]; bet[k] = v.current_round_bet[row0 + seat];
-            inv[k] = v.total_invested[row0 + seat]; status[k] = v.status[row0 + seat];
-            const int2 h = *reinterpret_cast<const int2*>(v.hands + (row0 + seat) * 2);
+            stack[k] = ldo(v.stacks, ro[k]); bet[k] = ldo(v.current_round_bet, ro[k]);
+            inv[k] = ldo(v.total_invested, ro[k]); status[k] = ldo(v.status, ro[k]);
+            const int2 h = ldo(reinterpret_cast<const int2*>(v.hands), ro[k] * 2u);
             h0[k] = h.x; h1[k] = h.y;
         }
-        if (seat < A) eq[k] = v.equities[(size_t)t * A + seat];
+        if (seat < A) eq[k] = ldo(v.equities, (ut * (uint32_t)A + (uint32_t)seat) * 4u);
     }
     long long act64 = 0;
-    if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = actions[t];
+    if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = ldo(actions, ut * 8u);
     // the Philox draw of this (table, step) depends on no load: issue it now, it executes under the load latency
     U4 rnd{0, 0, 0, 0};
     if (POLICY) rnd = philox4x32(pa.seed, pa.table_id0 + (uint64_t)t, pa.step_counter);
     const float w1 = *v.w1, w2 = *v.w2;
     const int Kdiv = *v.K, alpha = *v.alpha;
     uint32_t pre_tag = 0;
-    if ((PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board) pre_tag = (uint32_t)v.pre_board[t];
+    if ((PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board) pre_tag = (uint32_t)ldo(v.pre_board, so);
     // next street's cards, fetched now so the dependent deck read overlaps the policy / betting logic
     int nx0 = 0, nx1 = 0, nx2 = 0;
     if ((PH & PULSE_PH_ADVANCE) && kPrefetchDeck) {
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     const int a_status = SEAT_PICK(status, actor), a_stack = SEAT_PICK(stack, actor), a_bet = SEAT_PICK(bet, actor);
     const bool has_legal_actor = a_status != PULSE_FOLDED && a_status != PULSE_ALLIN && a_status != PULSE_SITOUT && !prev_done;
     int prev_invested = a_bet;
-    if (!(PH & PULSE_PH_CAPTURE)) prev_invested = v.prev_invested[t];
+    if (!(PH & PULSE_PH_CAPTURE)) prev_invested = ldo(v.prev_invested, so);
     const int prev_stack = a_stack;
 
     STAMP(2);   // first loads have arrived (actor values picked)
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         if (type != PULSE_AGENT_EXTERNAL) {
             const int seat_i = idx & 15;
             act64 = scripted_action(type, SEAT_PICK(h0, seat_i), SEAT_PICK(h1, seat_i), pot, rnd);
-            if (j == 0) actions[t] = act64;
+            if (j == 0) sto(actions, ut * 8u, (int64_t)act64);
         }
     }
     const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
@@ -347,8 +354,8 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
                 if (seat < A && street) {
                     bool hit = false;
                     if (cached_board) {       // both cache reads are independent single hops
-                        const uint32_t ph = (uint32_t)v.pre_hands[row0 + seat];
-                        const float pe = v.pre_eq[((size_t)t * 3 + (stage - 1)) * P + seat];
+                        const uint32_t ph = (uint32_t)ldo(v.pre_hands, ro[k]);
+                        const float pe = ldo(v.pre_eq, ((ut * 3u + (uint32_t)(stage - 1)) * (uint32_t)P + (uint32_t)seat) * 4u);
                         hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
                         e = pe;
                     }
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
                     }
                 }
                 eq[k] = e;
-                if (seat < A) v.equities[(size_t)t * A + seat] = e;
+                if (seat < A) sto(v.equities, (ut * (uint32_t)A + (uint32_t)seat) * 4u, e);
             }
             dirty = false;
         }
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
                 if (eligible[k]) {
                     bool hit = false;
                     if (cached_board) {
-                        const uint32_t ph = (uint32_t)v.pre_hands[row0 + seat];
-                        const int pr = v.pre_rank[row0 + seat];
+                        const uint32_t ph = (uint32_t)ldo(v.pre_hands, ro[k]);
+                        const int pr = ldo(v.pre_rank, ro[k]);
                         hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
                         rank[k] = pr;
                     }
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         const float x = __fdiv_rn(__fadd_rn(__fmul_rn(w1, m), __fmul_rn(w2, sv)), (float)Kdiv);
         float r = __fmul_rn((float)alpha, tanh_rn(x));
         if ((PH & PULSE_PH_CAPTURE) && (!has_legal_actor || prev_done)) r = 0.0f;
-        if (j == 0) rewards[t] = r;
+        if (j == 0) sto(rewards, so, r);
     }
 
     STAMP(8);   // reward done
@@ -560,7 +567,8 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
     if (PH & PULSE_PH_OBS) {
         const int wlane = threadIdx.x & 63;
         float* const l_obs = reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * 16 * v.obs_size;
-        float* __restrict__ o = WOBS ? l_obs + (wlane >> 2) * v.obs_size : v.obs + (size_t)t * v.obs_size;
+        float* __restrict__ o = WOBS ? l_obs + (wlane >> 2) * v.obs_size
+                                     : reinterpret_cast<float*>(reinterpret_cast<char*>(v.obs) + ut * (uint32_t)v.obs_size * 4u);
         const int seat_i = idx & 15;
         const int n_h0 = SEAT_PICK(h0, seat_i), n_h1 = SEAT_PICK(h1, seat_i);
         const int n_stack = SEAT_PICK(stack, seat_i), n_status = SEAT_PICK(status, seat_i), n_bet = SEAT_PICK(bet, seat_i);
@@ -622,10 +630,10 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         const int seat = j + LPT * k;
         const bool changed = (stack[k] != stack_in[k]) | (bet[k] != bet_in[k]) | (inv[k] != inv_in[k]) | (status[k] != status_in[k]);
         if (seat < P && changed) {
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.stacks[row0 + seat] = stack[k];
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.current_round_bet[row0 + seat] = bet[k];
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) v.total_invested[row0 + seat] = inv[k];
-            if (PH & PULSE_PH_EXECUTE) v.status[row0 + seat] = status[k];
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(v.stacks, ro[k], stack[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(v.current_round_bet, ro[k], bet[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) sto(v.total_invested, ro[k], inv[k]);
+            if (PH & PULSE_PH_EXECUTE) sto(v.status, ro[k], status[k]);
         }
     }
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
@@ -634,26 +642,26 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
 #pragma unroll
             for (int c0 = 0; c0 < 5; c0 += LPT) {
                 const int c = c0 + j;
-                if (c < 5) v.board[t * 5 + c] = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4;
+                if (c < 5) sto(v.board, bo + (uint32_t)c * 4u, c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : c == 3 ? b3 : b4);
             }
         }
     }
     if (j == 0) {
-        if (PH & PULSE_PH_CAPTURE) { v.prev_stacks[t] = prev_stack; v.prev_invested[t] = prev_invested; }
+        if (PH & PULSE_PH_CAPTURE) { sto(v.prev_stacks, so, prev_stack); sto(v.prev_invested, so, prev_invested); }
         const bool betting_changed = (pot != pot_in) | (highest != highest_in) | (agg != agg_in) | (acted != acted_in) |
                                      (lrs != lrs_in) | (idx != idx_in);
         if (betting_changed) {
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) v.pots[t] = pot;
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) v.highest[t] = highest;
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { v.agg[t] = agg; v.acted[t] = acted; v.last_raise_size[t] = lrs; }
-            if (PH & PULSE_PH_ADVANCE) v.idx[t] = idx;
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(v.pots, so, pot);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(v.highest, so, highest);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { sto(v.agg, so, agg); sto(v.acted, so, acted); sto(v.last_raise_size, so, lrs); }
+            if (PH & PULSE_PH_ADVANCE) sto(v.idx, so, idx);
         }
         const bool street_changed = (stage != stage_in) | (dpos != dpos_in) | (dirty != dirty_in);
         if (street_changed) {
-            if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { v.stages[t] = stage; v.deck_positions[t] = dpos; }
-            if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) v.equity_dirty[t] = dirty ? 1 : 0;
+            if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { sto(v.stages, so, stage); sto(v.deck_positions, so, dpos); }
+            if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) sto(v.equity_dirty, ut, (uint8_t)(dirty ? 1 : 0));
         }
-        if (PH & PULSE_PH_ADVANCE) v.is_done_out[t] = done ? 1 : 0;      // ping-pong buffer: always written
+        if (PH & PULSE_PH_ADVANCE) sto(v.is_done_out, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
     }
     STAMP(10);  // state stores issued
 #if PULSE_STAMPS
@@ -900,17 +908,6 @@ int lanes_per_table() {
     return g_lpt;
 }
 
-int g_stagger = -1;
-int stagger_knob() {
-    if (g_stagger < 0) { const char* e = getenv("PULSE_STAGGER"); g_stagger = e ? atoi(e) : 0; }
-    return g_stagger;
-}
-int g_lds_pad = -1;
-int lds_pad() {      // experiment knob: dynamic LDS bytes per workgroup, only to cap workgroups per CU
-    if (g_lds_pad < 0) { const char* e = getenv("PULSE_LDS_PAD"); g_lds_pad = e ? atoi(e) : 0; }
-    return g_lds_pad;
-}
-
 int g_wobs = -1;
 bool obs_staging_enabled() {
     if (g_wobs < 0) { const char* e = getenv("PULSE_WOBS"); g_wobs = (e && atoi(e) == 0) ? 0 : 1; }
@@ -922,24 +919,23 @@ void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor
                  hipStream_t st) {
     const int lpt = lanes_per_table();
     const dim3 grid((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)), block(kBlock);
-    const int pad = lds_pad();
     const int spl = (v.max_players + lpt - 1) / lpt;   // seats per lane needed to cover max_players (obs padding too)
-    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    if (lpt == 16) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 16, 1, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 1) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 1, 16, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2 && spl <= 5) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 5, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else if (lpt == 2) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 2, 8, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
     else if (PH == PULSE_PH_STEP && obs_staging_enabled() && (v.n_games & 15) == 0 && ((uintptr_t)v.obs & 15u) == 0) {
         const size_t lds = sizeof(float) * (size_t)(kBlock / 64) * 16 * (size_t)v.obs_size;
         if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3, PH == PULSE_PH_STEP>), grid, block, lds, st, v, actions, actor_idx, rewards, pa);
         else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4, PH == PULSE_PH_STEP>), grid, block, lds, st, v, actions, actor_idx, rewards, pa);
     }
-    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
-    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4, false>), grid, block, pad, st, v, actions, actor_idx, rewards, pa);
+    else if (spl <= 3) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 3, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, 4, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa);
 }
 
 template <uint32_t PH>
 void launch_phase(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, hipStream_t st) {
-    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0, 0}, st);
+    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0}, st);
 }
 
 }  // namespace
@@ -959,7 +955,7 @@ int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types,
     if (int rc = check_view(v, "pulse_poker_policy_step")) return rc;
     if (!actions || !rewards || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_policy_step: null argument");
     if (v->n_games == 0) return 0;
-    const PolicyArgs pa{pack_types(agent_types, v->n_players), seed, step_counter, table_id0, stagger_knob()};
+    const PolicyArgs pa{pack_types(agent_types, v->n_players), seed, step_counter, table_id0};
     launch_step<PULSE_PH_STEP, true>(*v, actions, nullptr, rewards, pa, (hipStream_t)stream);
     return finish_launch("pulse_poker_policy_step");
 }
@@ -996,7 +992,7 @@ int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* action
                        uint64_t step_counter, void* stream) {
     if (int rc = check_view(v, "pulse_poker_ablate")) return rc;
     const dim3 grid((unsigned)(((long long)v->n_games * 4 + kBlock - 1) / kBlock)), block(kBlock);
-    const PolicyArgs pa{types_packed, 1, step_counter, 0, 0};
+    const PolicyArgs pa{types_packed, 1, step_counter, 0};
     hipStream_t st = (hipStream_t)stream;
 #define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 4, 3, false>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa); break;
     switch (phases) {
@@ -1093,7 +1089,7 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     for (int i = 0; i < n_steps; ++i) {
         const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
         float* rw = (i & 1) ? rewards_odd : rewards_even;
-        const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0, stagger_knob()};
+        const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0};
         launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
     }
     if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); g_ev_launches[g_ev_used] = n_steps; ++g_ev_used; }

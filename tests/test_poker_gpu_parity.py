@@ -430,3 +430,69 @@ def test_poker_reward_gpu_contracts_and_oracle(oracle_table):
     want = np.array([orc.lib().oracle_reward(C.byref(s), C.c_int(t), C.c_int64(int(acts[t])), C.c_int(int(actor[t]))) for t in range(N)],
                     dtype=np.float32)
     np.testing.assert_allclose(got, want, rtol=0, atol=reward_tol(11))
+
+
+def test_scripted_policy_masks_and_distributions():
+    """build_actions semantics of the scripted opponents (Player.py:79-176, utils.py:108-123) on the stand-alone
+    policy kernel: deterministic masks bit-exact against a Python restatement of the rules, random picks inside the
+    reference's ranges with (roughly) uniform frequencies."""
+    from pulselib_amd.environments.Poker.utils import launch_policy, set_policy_seed
+    N = 200000
+    rng = np.random.default_rng(12)
+    obs = np.zeros((N, 40), dtype=np.float32)
+    obs[:, 5] = rng.integers(1, 53, N); obs[:, 6] = rng.integers(1, 53, N); obs[:, 9] = rng.integers(0, 160, N)
+    seat = rng.integers(0, 6, N).astype(np.int32)
+    types = [0, 1, 2, 3, 4, 5]                       # seat k is played by native type k (0 = external)
+    actions = torch.full((N,), -7, dtype=torch.long, device=DEV)
+    set_policy_seed(4242)
+    launch_policy(torch.from_numpy(obs).to(DEV), actions, torch.from_numpy(seat).to(DEV), types, step_counter=3)
+    a = actions.cpu().numpy()
+    r1, r2, pot = obs[:, 5].astype(int) % 13, obs[:, 6].astype(int) % 13, obs[:, 9]
+    d, pair = np.abs(r1 - r2), r1 == r2
+    big = pair | ((r1 >= 10) & (r2 > 5)) | ((r2 >= 10) & (r1 > 5))
+    m = seat == 0
+    assert (a[m] == -7).all()                                                    # external seats untouched
+    m = seat == 1
+    assert a[m].min() == 0 and a[m].max() == 12
+    assert np.bincount(a[m], minlength=13).min() > 0.85 * m.sum() / 13           # randint(0, 13)
+    m = seat == 2                                                                # heuristic_hands
+    fold = (r1 < 8) & (r2 < 8); raise_ = (pair | (r1 >= 10) | (r2 >= 10)) & ~fold
+    assert (a[m & ~raise_] == 0).all() and ((a[m & raise_] >= 2) & (a[m & raise_] <= 10)).all()
+    assert np.bincount(a[m & raise_], minlength=11)[2:].min() > 0.8 * (m & raise_).sum() / 9
+    m = seat == 3                                                                # tight_aggressive
+    fold = (r1 < 7) & (r2 < 7) & (d > 5); raise_ = big & ~fold
+    assert (a[m & fold] == 0).all() and (a[m & ~fold & ~raise_] == 1).all()
+    assert ((a[m & raise_] >= 7) & (a[m & raise_] <= 10)).all()
+    m = seat == 4                                                                # loose_passive
+    call = (pair & (r1 > 8)) | ((r1 >= 11) & (r2 > 9)) | ((r2 >= 11) & (r1 > 9))
+    assert (a[m & ~call] == 0).all() and ((a[m & call] == 1) | ((a[m & call] >= 2) & (a[m & call] <= 5))).all()
+    frac_raise = (a[m & call] >= 2).mean()
+    assert 0.06 < frac_raise < 0.14                                              # rand() > 0.9
+    m = seat == 5                                                                # small_ball
+    fold = ((r1 < 6) & (r2 < 6) & (pot > 30)) | ((r1 < 9) & (r2 < 9) & (pot > 80)); raise_ = big & ~fold
+    assert (a[m & ~raise_] == 0).all() and ((a[m & raise_] >= 2) & (a[m & raise_] <= 4)).all()
+
+
+def test_hip_matches_oracle_at_config4_shard_size(oracle_table):
+    """BASELINE.json config 4: 1,048,576 tables over 8 GPUs = 131,072 per GPU (global table ids of rank 3)."""
+    from oracle import oracle as orc
+    from pulselib_amd.sharding import shard_tables
+    n_local, t0 = shard_tables(1048576, 8, 3)
+    kw = dict(n_players=10, max_players=10, n_games=n_local, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
+    env = _gpu_env(seed=20260401, table_id0=t0, **kw)
+    ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
+    types = [1, 3, 2, 2, 4, 3, 1, 4, 5, 3]
+    env.reset(options={"active_players": 9, "rotation": 2})          # device shuffle keyed by global table ids
+    decks = env.decks.cpu().numpy()
+    ref.reset(options={"active_players": 9, "rotation": 2, "prefixed_decks": decks})
+    a_gpu = torch.zeros(n_local, dtype=torch.long, device=DEV)
+    a_ref = np.zeros(n_local, dtype=np.int64)
+    for s in range(24):
+        env.policy_step(types, a_gpu, 500 + s)
+        ref.policy_step(types, 20260401, 500 + s, a_ref, table_id0=t0)
+        assert_state_equal(_snap(env), ref.snapshot(), ctx=f"shard step {s}")
+        np.testing.assert_array_equal(to_np(env.obs), ref.obs, err_msg=f"shard step {s}")
+    # size-independent property: chips only move between stacks and pots (no showdown layer was dropped here
+    # unless a folded player out-invested every contender, which the oracle reproduces identically)
+    total = to_np(env.stacks).sum(dtype=np.int64) + to_np(env.pots).sum(dtype=np.int64)
+    assert total == ref.stacks.sum(dtype=np.int64) + ref.pots.sum(dtype=np.int64)
