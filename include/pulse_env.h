@@ -125,12 +125,16 @@ int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* 
  *   prefixed_decks : device int32[N,52] copied into v->decks, or NULL = shuffle on device with
  *                    Philox4x32-10(seed, table id + table_id0, episode) (replaces rand().argsort, :86)
  *   decks_out      : v->decks is const in the view; reset writes through this pointer.
- *   rotation       : torch.roll shift of the stack rows                                     (:104-110) */
+ *   rotation       : torch.roll shift of the stack rows                                     (:104-110)
+ *   shuffle_key_bits : the device shuffle ranks 52 Philox words per table, equal words keeping card order;
+ *                    0 (or >= 32) uses whole words.  A small value keeps only that many top bits and so
+ *                    forces ties: a hook for the tests of the tie-break, not for production use. */
 typedef struct PulsePokerResetOpts {
     int32_t first, starting_bbs, max_bbs, rotation;
     uint64_t seed, episode, table_id0;
     const int32_t* prefixed_decks;
     int32_t* decks_out;
+    int32_t shuffle_key_bits, reserved0;
 } PulsePokerResetOpts;
 int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream);
 

@@ -242,6 +242,14 @@ def eval_hands(hr: np.ndarray, cards: np.ndarray) -> np.ndarray:
     return out
 
 
+def shuffle_decks(seed: int, table_id0: int, episode: int, n_tables: int, key_bits: int = 0) -> np.ndarray:
+    """The device shuffle's definition (oracle/poker_oracle.c: oracle_shuffle_decks) -> int32[n_tables, 52]."""
+    decks = np.zeros((n_tables, 52), dtype=np.int32)
+    lib().oracle_shuffle_decks(C.c_uint64(seed), C.c_uint64(table_id0), C.c_uint64(episode), C.c_int(key_bits),
+                               C.c_int(n_tables), decks.ctypes.data_as(C.c_void_p))
+    return decks
+
+
 def philox4x32(seed: int, subseq: int, offset: int) -> np.ndarray:
     out = np.zeros(4, dtype=np.uint32)
     lib().oracle_philox4x32(C.c_uint64(seed), C.c_uint64(subseq), C.c_uint64(offset), out.ctypes.data_as(C.c_void_p))

@@ -425,6 +425,30 @@ void oracle_eval_hands(const int32_t* hr, int64_t hr_len, const int32_t* cards, 
  * 2 heuristic_hands, 3 tight_aggressive, 4 loose_passive, 5 small_ball. */
 void oracle_philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset, uint32_t out[4]);
 
+/* ---- deck shuffle (replaces torch.rand(N,52).argsort(dim=1)+1, PokerGPU.py:86) -----------------
+ * The framework's own definition (the reference's draw is not reproducible across devices): card c
+ * (0..51) gets key word (c & 3) of Philox4x32-10(seed, global table id, episode*16 + (c >> 2)),
+ * optionally cut to its top key_bits bits; the deck lists cards + 1 by ascending key, equal keys in
+ * card order (a stable sort -- here an insertion sort, the HIP kernels count ranks instead). */
+void oracle_shuffle_decks(uint64_t seed, uint64_t table_id0, uint64_t episode, int key_bits, int n_tables,
+                          int32_t* decks) {
+    const int shift = (key_bits > 0 && key_bits < 32) ? 32 - key_bits : 0;
+    for (int t = 0; t < n_tables; t++) {
+        uint32_t key[52]; int32_t* d = decks + (size_t)t * 52;
+        for (int s = 0; s < 13; s++) {
+            uint32_t r[4];
+            oracle_philox4x32(seed, table_id0 + (uint64_t)t, episode * 16 + (uint64_t)s, r);
+            for (int q = 0; q < 4; q++) key[4 * s + q] = r[q] >> shift;
+        }
+        int n = 0;
+        for (int c = 0; c < 52; c++) {                      /* insert card c after every key <= its own */
+            int i = n++;
+            while (i > 0 && key[d[i - 1] - 1] > key[c]) { d[i] = d[i - 1]; i--; }
+            d[i] = c + 1;
+        }
+    }
+}
+
 static int rand_below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)n) >> 32); }
 
 int oracle_scripted_action(int type, int c1, int c2, int pot, const uint32_t rnd[4]) {

@@ -48,7 +48,8 @@ class PokerView(C.Structure):
 class PokerResetOpts(C.Structure):
     _fields_ = [("first", C.c_int32), ("starting_bbs", C.c_int32), ("max_bbs", C.c_int32), ("rotation", C.c_int32),
                 ("seed", C.c_uint64), ("episode", C.c_uint64), ("table_id0", C.c_uint64),
-                ("prefixed_decks", C.c_void_p), ("decks_out", C.c_void_p)]
+                ("prefixed_decks", C.c_void_p), ("decks_out", C.c_void_p),
+                ("shuffle_key_bits", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class QTable(C.Structure):

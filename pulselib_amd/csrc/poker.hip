@@ -60,6 +60,13 @@ __device__ __forceinline__ int first_after(uint32_t bits, int x, int A) {
 __device__ __forceinline__ int hr_at(const int32_t* __restrict__ hr, uint32_t len, int i) {
     return (uint32_t)i < len ? hr[(uint32_t)i] : 0;
 }
+// same value, but the load is unconditional (index clamped to slot 0, result masked): independent lookups
+// written back to back stay back to back in the instruction stream instead of becoming branches
+__device__ __forceinline__ int hr_at_nb(const int32_t* __restrict__ hr, uint32_t len, int i) {
+    const bool ok = (uint32_t)i < len;
+    const int x = hr[ok ? (uint32_t)i : 0u];
+    return ok ? x : 0;
+}
 // seven dependent gathers: p = HR[p + c_i], p0 = 53 (PokerGPU.py:437-444).  A card of 0 re-reads
 // slot 0 of the state, which is exactly the extra HR[p] / HR[HR[p]] lookups of the turn / flop
 // equities (PokerGPU.py:500, :521), so all three streets share one 7-step chain.
@@ -210,6 +217,8 @@ constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0
 PULSE_GRP_REDUCE(grp_or, uint32_t, PULSE_OP_OR)
 PULSE_GRP_REDUCE(grp_imin, int, PULSE_OP_MIN)
 PULSE_GRP_REDUCE(grp_imax, int, PULSE_OP_MAX)
+#define PULSE_OP_ADD(a, b) ((a) + (b))
+PULSE_GRP_REDUCE(grp_sum, int, PULSE_OP_ADD)
 // x mod A for x that is almost always within one period of [0, A): two conditional corrections,
 // integer division only on the (poked-state) slow path.
 __device__ __forceinline__ int mod_near(int x, int A) {
@@ -706,6 +715,11 @@ __global__ __launch_bounds__(kBlock) void poker_eval_kernel(const int32_t* __res
 }
 
 // ---------------------------------------------------------------- reset (PokerGPU.py:73-157)
+// shuffle keys keep their top `shuffle_key_bits` bits (0 = all 32; fewer bits force ties, for the tests)
+__device__ __forceinline__ int key_shift(const PulsePokerResetOpts& o) {
+    return (o.shuffle_key_bits > 0 && o.shuffle_key_bits < 32) ? 32 - o.shuffle_key_bits : 0;
+}
+
 template <bool SHUFFLE>
 __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerView v, const PulsePokerResetOpts o) {
     __shared__ uint32_t keys[kBlock / kLanes][52];
@@ -724,18 +738,39 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     if (SHUFFLE) {
         if (s < 13) {
             const U4 r = philox4x32(o.seed, o.table_id0 + (uint64_t)t, o.episode * 16 + (uint64_t)s);
-            keys[g][4 * s + 0] = r.x; keys[g][4 * s + 1] = r.y; keys[g][4 * s + 2] = r.z; keys[g][4 * s + 3] = r.w;
+            const int ks = key_shift(o);
+            keys[g][4 * s + 0] = r.x >> ks; keys[g][4 * s + 1] = r.y >> ks; keys[g][4 * s + 2] = r.z >> ks; keys[g][4 * s + 3] = r.w >> ks;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // card c (0..51) lands at position #{keys < key[c]} (ties by index): deck[pos] = c + 1
+        // card c (0..51) lands at position #{keys < key[c]} (ties by index): deck[pos] = c + 1.  Without a tie
+        // the strict count alone is the position (one compare + one add-with-carry per pair); with one, the
+        // table's strict counts sum to less than 0 + 1 + ... + 51 and the wavefront (rarely: ~3e-7 per table)
+        // recounts with the index tie-break.
+        uint32_t kc[4] = {0, 0, 0, 0}; int pos[4] = {0, 0, 0, 0};
         if (s < 13) {
-            for (int q = 0; q < 4; ++q) {
-                const int c = 4 * s + q;
-                const uint32_t kc = keys[g][c];
-                int pos = 0;
-                for (int j = 0; j < 52; ++j) { const uint32_t kj = keys[g][j]; pos += (kj < kc) || (kj == kc && j < c); }
-                deck_s[g][pos] = c + 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kc[q] = keys[g][4 * s + q];
+            for (int j = 0; j < 52; ++j) {
+                const uint32_t kj = keys[g][j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pos[q] += kj < kc[q];
             }
+        }
+        const int psum = grp_sum<kLanes>(pos[0] + pos[1] + pos[2] + pos[3]);
+        if (__any(psum != 1326)) {
+            if (s < 13) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pos[q] = 0;
+                for (int j = 0; j < 52; ++j) {
+                    const uint32_t kj = keys[g][j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pos[q] += (kj < kc[q]) || (kj == kc[q] && j < 4 * s + q);
+                }
+            }
+        }
+        if (s < 13) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) deck_s[g][pos[q]] = 4 * s + q + 1;
         }
     } else {
         const int32_t* src = o.prefixed_decks + (size_t)t * 52;
@@ -773,11 +808,12 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
             p3 = hr_at(hr, hr_len, p3 + f0); p3 = hr_at(hr, hr_len, p3 + f1); p3 = hr_at(hr, hr_len, p3 + f2);
             const int p4 = hr_at(hr, hr_len, p3 + f3);
             const int p5 = hr_at(hr, hr_len, p4 + f4);
-            const int q5 = hr_at(hr, hr_len, hr_at(hr, hr_len, p3 + h0) + h1);
-            const int q6 = hr_at(hr, hr_len, hr_at(hr, hr_len, p4 + h0) + h1);
-            const int r7 = hr_at(hr, hr_len, hr_at(hr, hr_len, p5 + h0) + h1);
-            const float vf = (float)hr_at(hr, hr_len, hr_at(hr, hr_len, q5));               // :521
-            const float vt = (float)hr_at(hr, hr_len, q6);                                  // :500
+            // three independent chains, issued level by level (unconditional loads: no branch between them)
+            const int a1 = hr_at_nb(hr, hr_len, p3 + h0), b1 = hr_at_nb(hr, hr_len, p4 + h0), c1 = hr_at_nb(hr, hr_len, p5 + h0);
+            const int q5 = hr_at_nb(hr, hr_len, a1 + h1), q6 = hr_at_nb(hr, hr_len, b1 + h1), r7 = hr_at_nb(hr, hr_len, c1 + h1);
+            const int a3 = hr_at_nb(hr, hr_len, q5);
+            const float vt = (float)hr_at_nb(hr, hr_len, q6);                               // :500
+            const float vf = (float)hr_at_nb(hr, hr_len, a3);                               // :521
             float ef = __fdiv_rn(__fsub_rn(vf, 74359.0f), 749420.0f);                       // :523
             float et = __fdiv_rn(__fsub_rn(vt, 4109.0f), 32765.0f);                         // :502
             float er = __fdiv_rn(__fsub_rn((float)r7, 4109.0f), 32765.0f);                  // :481

@@ -285,6 +285,7 @@ class PokerGPU(_EnvBase):
         o.seed, o.episode, o.table_id0 = self.seed & (2**64 - 1), self.episode, self.table_id0
         o.prefixed_decks = deck_tensor.data_ptr() if deck_tensor is not None else None
         o.decks_out = self.decks.data_ptr()
+        o.shuffle_key_bits = int(getattr(self, "_shuffle_key_bits", 0))      # test hook (pulse_env.h)
         _native.check(self._lib.pulse_poker_reset(C.byref(v), C.byref(o), self._stream()), "pulse_poker_reset")
         self.button_pos = self.button[0]
         self._has_episode = True

@@ -76,3 +76,16 @@ def test_q_helpers_follow_utils_numba():
     lib.oracle_update_q_entry(cur.ctypes.data_as(C.c_void_p), 0, nxt.ctypes.data_as(C.c_void_p), 4, C.c_double(0.5), C.c_double(-2.0),
                               C.c_double(0.99), 1)
     assert cur[0] == 1.0 + 0.5 * (-2.0 - 1.0)                       # terminal: target = reward
+
+
+def test_oracle_shuffle_is_stable_argsort_of_philox_keys():
+    """oracle_shuffle_decks (the definition the HIP reset kernels are held to) against numpy: deck = stable
+    argsort of the 52 Philox key words + 1, also with keys cut to few bits (ties everywhere)."""
+    from oracle import oracle as orc
+    n, seed, id0, ep = 48, 31337, 1 << 33, 7
+    keys = np.array([[orc.philox4x32(seed, id0 + t, ep * 16 + s) for s in range(13)] for t in range(n)],
+                    dtype=np.uint32).reshape(n, 52)
+    for bits in (0, 32, 6, 1):
+        k = keys >> (32 - bits) if 0 < bits < 32 else keys
+        want = np.argsort(k, axis=1, kind="stable").astype(np.int32) + 1
+        np.testing.assert_array_equal(orc.shuffle_decks(seed, id0, ep, n, bits), want)

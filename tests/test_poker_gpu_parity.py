@@ -254,6 +254,28 @@ def test_device_shuffle_gives_permutations():
     np.testing.assert_array_equal(env2.decks.cpu().numpy(), d1)    # same seed, same tables -> same decks
 
 
+@pytest.mark.parametrize("N", [4096, 4090], ids=["quad-per-table", "16-lanes-ragged"])
+@pytest.mark.parametrize("key_bits", [0, 5, 1], ids=["full-keys", "5-bit-ties", "1-bit-ties"])
+def test_device_shuffle_matches_oracle_definition(oracle_table, N, key_bits):
+    """Decks of the on-device shuffle, bit-exact against oracle_shuffle_decks (stable sort of the Philox keys) for
+    both reset kernels (a table count off a multiple of 16 takes the 16-lanes-per-table one); cut keys force ties in
+    every table and so exercise the tie-break / recount path.  The rest of the reset state follows from the decks
+    and is checked against the oracle fed the same decks."""
+    from oracle import oracle as orc
+    P, seed, id0 = 10, 77, 123456
+    env = _gpu_env(n_players=P, max_players=P, n_games=N, seed=seed, table_id0=id0)
+    env._shuffle_key_bits = key_bits
+    ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=8, n_players=P, max_players=P, n_games=N)
+    for ep, A in enumerate((6, 10, 2)):
+        env.reset(options={"active_players": A, "rotation": ep})
+        want = orc.shuffle_decks(seed, id0, ep, N, key_bits)
+        np.testing.assert_array_equal(to_np(env.decks), want, err_msg=f"episode {ep}")
+        ref.reset(options={"active_players": A, "rotation": ep, "prefixed_decks": want})
+        assert ref.active_players == A
+        assert_state_equal(_snap(env), ref.snapshot(), ctx=f"episode {ep}")
+        np.testing.assert_array_equal(to_np(env.obs), ref.obs)
+
+
 # ---- the reference's own known answers (tests/scenarios.py) on the HIP path ------------------------
 from tests.scenarios import SCENARIOS  # noqa: E402
 from tests.test_known_answers import run_scenario  # noqa: E402
