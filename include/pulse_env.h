@@ -217,6 +217,27 @@ int pulse_qtable_update(const PulseQTable* q, const int64_t* slots, const int64_
                         const int32_t* next_boards, const uint8_t* terminal, int32_t n_boards, int32_t n, double alpha,
                         double gamma, void* stream);
 
+/* ---- the learner's action selection (environments/Poker/Player.py:178-253) ---------------------
+ * PokerQNetwork.network in eval mode: Linear(state_dim,128) GELU Linear(128,128) GELU [Dropout] Linear(128,64)
+ * GELU [Dropout] Linear(64,32) GELU Linear(32,n_actions) (:189-201).  Weights are the module's own tensors:
+ * torch.nn.Linear layout w[out][in] row-major fp32 on the device, 16-byte aligned; nothing is packed or cached
+ * between calls, so an optimizer step is visible to the next call. */
+typedef struct PulseQNet {
+    int32_t state_dim, n_actions;                       /* n_actions <= 32 */
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *w5, *b5;
+} PulseQNet;
+/* q_out[r, :] = network(states[r, :]) (Player.py:235-240); states fp32 rows of state_dim at row_stride floats. */
+int pulse_qnet_forward(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows, float* q_out,
+                       void* stream);
+/* PokerQNetwork.get_actions (Player.py:242-253) fused with build_actions' mask (utils.py:108-119): for every row
+ * r with seat_idx[r] == q_seat (seat_idx NULL: every row) actions[r] = uniform{0..n_actions-1} with probability
+ * epsilon, else the first argmax of the Q row; other rows are left untouched.  Draws are words x (explore) and y
+ * (action) of Philox4x32-10(seed, table_id0 + r, step), the stream pulse_poker_policy uses for scripted seats.
+ * q_out NULL or fp32[n_rows, n_actions] (selected rows written). */
+int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows,
+                   const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
+                   uint64_t table_id0, int64_t* actions, float* q_out, void* stream);
+
 /* ---- Particle2D (environments/Particle2D/Particle2D.py:22-30) ---------------------------------- */
 int pulse_particle2d_step(float* state, const float* action, int32_t* steps, float* obs_out, float* rewards,
                           uint8_t* terminated, int32_t n, float dt, int32_t max_steps, void* stream);

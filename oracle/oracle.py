@@ -250,6 +250,39 @@ def shuffle_decks(seed: int, table_id0: int, episode: int, n_tables: int, key_bi
     return decks
 
 
+def _qnet_ptrs(weights, biases):
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    arr_w = (C.c_void_p * 5)(*[w.ctypes.data for w in ws])
+    arr_b = (C.c_void_p * 5)(*[b.ctypes.data for b in bs])
+    return ws, bs, arr_w, arr_b
+
+
+def qnet_forward(weights, biases, states: np.ndarray) -> np.ndarray:
+    """oracle/qnet_oracle.c: PokerQNetwork.network in eval mode; weights/biases = the five Linear layers (torch layout)."""
+    ws, bs, arr_w, arr_b = _qnet_ptrs(weights, biases)
+    states = np.ascontiguousarray(states, dtype=np.float32)
+    n, k = states.shape
+    assert ws[0].shape == (128, k)
+    n_actions = ws[4].shape[0]
+    out = np.zeros((n, n_actions), dtype=np.float32)
+    lib().oracle_qnet_forward(C.c_int(k), C.c_int(n_actions), arr_w, arr_b, states.ctypes.data_as(C.c_void_p), C.c_long(k),
+                              C.c_int(n), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def qnet_act(q: np.ndarray, seat_idx, q_seat: int, epsilon: float, seed: int, step: int, table_id0: int,
+             actions: np.ndarray) -> np.ndarray:
+    """oracle/qnet_oracle.c: epsilon-greedy over Q rows for the rows of the learner's seat; `actions` updated in place."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    assert actions.dtype == np.int64 and actions.flags["C_CONTIGUOUS"]
+    si = None if seat_idx is None else np.ascontiguousarray(seat_idx, dtype=np.int32)
+    lib().oracle_qnet_act(C.c_int(q.shape[1]), q.ctypes.data_as(C.c_void_p), C.c_int(q.shape[0]),
+                          None if si is None else si.ctypes.data_as(C.c_void_p), C.c_int(q_seat), C.c_float(epsilon),
+                          C.c_uint64(seed), C.c_uint64(step), C.c_uint64(table_id0), actions.ctypes.data_as(C.c_void_p))
+    return actions
+
+
 def philox4x32(seed: int, subseq: int, offset: int) -> np.ndarray:
     out = np.zeros(4, dtype=np.uint32)
     lib().oracle_philox4x32(C.c_uint64(seed), C.c_uint64(subseq), C.c_uint64(offset), out.ctypes.data_as(C.c_void_p))

@@ -52,6 +52,11 @@ class PokerResetOpts(C.Structure):
                 ("shuffle_key_bits", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class QNet(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("n_actions", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "w5", "b5")]
+
+
 class QTable(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("capacity", C.c_uint64), ("region_slots", C.c_uint64)]
 
@@ -64,7 +69,7 @@ class BlackjackView(C.Structure):
 
 
 # every symbol include/pulse_env.h declares: (restype, argtypes)
-_P, _I32, _U32, _U64, _F32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float
+_P, _I32, _U32, _U64, _F32, _I64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float, C.c_int64
 SYMBOLS = {
     "pulse_version": (C.c_int, []),
     "pulse_last_error": (C.c_char_p, []),
@@ -87,6 +92,8 @@ SYMBOLS = {
     "pulse_qtable_select": (C.c_int, [_P, _P, _I32, _I32, C.c_double, _U64, _U64, _U64, _P, _P, _P]),
     "pulse_qtable_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, C.c_double, C.c_double, _P]),
     "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
+    "pulse_qnet_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P]),
 }
 
 

@@ -11,6 +11,7 @@ import torch
 
 from ... import _native
 from . import utils as _utils
+from .qnetwork import PokerQNetwork  # noqa: F401  (environments/Poker/Player.py:178 lives here in the reference)
 
 
 class Player:

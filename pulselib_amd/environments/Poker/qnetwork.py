@@ -1,0 +1,200 @@
+"""The learner of the Poker GPU trainer: `PokerQNetwork` with the reference's constructor, attribute and
+method names (environments/Poker/Player.py:178-298), so checkpoints (`network.state_dict()`), the trainer
+loop (scripts/Poker/trainGPU.py:57-108) and the tests' DummyPokerQNetwork subclasses carry over.
+
+What is native here:
+  * action selection -- `get_actions`, and the fused masked form `act_into` used by `build_actions` -- is one
+    MFMA kernel (csrc/qnet.hip) reading the module's own weight tensors; no mask gather / scatter, no
+    host sync, draws keyed by (seed, global table id, step) like the scripted opponents';
+  * `train_step_masked`, the sync-free form of `train_step`: the reference filters rows with boolean indexing
+    (a device->host sync per mask); here every row goes through with a 0/1 weight, so the loss, the clipped
+    gradient and the AdamW update are those of the filtered batch while nothing waits on the host.
+`train_step` itself keeps the reference's filtering semantics verbatim (Player.py:255-294); both run on
+PyTorch-ROCm autograd (the learner's GEMMs are PyTorch plumbing for now)."""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from ... import _native
+
+HIDDEN = (128, 128, 64, 32)      # Player.py:189-201
+
+
+def build_network(state_dim: int, action_dim: int) -> nn.Sequential:
+    """Same module indices as the reference's Sequential (0,2,5,8,10 Linear; 4,7 Dropout), so state_dicts interchange."""
+    h1, h2, h3, h4 = HIDDEN
+    return nn.Sequential(
+        nn.Linear(state_dim, h1), nn.GELU(),
+        nn.Linear(h1, h2), nn.GELU(), nn.Dropout(.1),
+        nn.Linear(h2, h3), nn.GELU(), nn.Dropout(0.1),
+        nn.Linear(h3, h4), nn.GELU(),
+        nn.Linear(h4, action_dim),
+    )
+
+
+LINEAR_INDICES = (0, 2, 5, 8, 10)
+
+
+class PokerQNetwork(nn.Module):
+    def __init__(self, weights_path, device, gamma, update_freq: int, epsilon=.1, epsilon_end=.001, epsilon_decay=.99999,
+                 state_dim=27, action_dim=13, hidden_dim=256, learning_rate=1e-3, weight_decay=1e-3, seed=0, table_id0=0):
+        super().__init__()
+        del hidden_dim                       # accepted and unused, as in the reference (:179)
+        self.update_freq = update_freq
+        self.device = device
+        self.gamma = gamma
+        self.epsilon = epsilon
+        self.epsilon_decay = epsilon_decay
+        self.epsilon_end = epsilon_end
+        self.state_dim, self.action_dim = int(state_dim), int(action_dim)
+        self.network = build_network(self.state_dim, self.action_dim)
+        if weights_path and Path(weights_path).exists():
+            self.network.load_state_dict(torch.load(weights_path, map_location=device, weights_only=True))
+        self.target_network = copy.deepcopy(self.network)
+        self.target_network.eval()
+        self.lr = float(learning_rate)
+        self.wd = float(weight_decay)
+        self.step_count = 0
+        self.criterion = nn.MSELoss()
+        self.to(device)
+        self.optimizer = self.configure_optimizers()
+        # Philox keys of the exploration draws (act_into takes the env step counter; get_actions counts its calls)
+        self.seed, self.table_id0 = int(seed), int(table_id0)
+        self._calls = 0
+        self._lr_gate = None
+
+    # ------------------------------------------------------------------ torch side
+    def forward(self, states):
+        return self.network(states)
+
+    def configure_optimizers(self):
+        on_gpu = torch.device(self.device).type == "cuda"
+        return torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.wd, fused=on_gpu)
+
+    # ------------------------------------------------------------------ native action selection
+    def _net_struct(self, net: nn.Sequential) -> _native.QNet:
+        s = _native.QNet()
+        s.state_dim, s.n_actions = self.state_dim, self.action_dim
+        for i, li in enumerate(LINEAR_INDICES, start=1):
+            lin = net[li]
+            w, b = lin.weight, lin.bias
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and b.is_contiguous()):
+                raise RuntimeError("PokerQNetwork: action selection runs on the MI355X only (fp32 weights on a cuda device); "
+                                   "there is no CPU path")
+            setattr(s, f"w{i}", w.data_ptr())
+            setattr(s, f"b{i}", b.data_ptr())
+        return s
+
+    @staticmethod
+    def _rows(states):
+        if not (states.is_cuda and states.dtype == torch.float32 and states.dim() == 2 and states.stride(1) == 1):
+            if not states.is_cuda:
+                raise RuntimeError("PokerQNetwork: states must live on the GPU (no CPU path)")
+            states = states.to(torch.float32).contiguous()
+        return states
+
+    def _decay_epsilon(self):
+        self.epsilon = max(self.epsilon * self.epsilon_decay, self.epsilon_end)      # Player.py:243
+
+    def q_values(self, states, target: bool = False):
+        """network(states) in eval mode through the HIP kernel -> fp32[n, action_dim] (no autograd)."""
+        states = self._rows(states)
+        out = torch.empty((states.shape[0], self.action_dim), dtype=torch.float32, device=states.device)
+        net = self._net_struct(self.target_network if target else self.network)
+        _native.check(_native.lib().pulse_qnet_forward(C.byref(net), states.data_ptr(), states.stride(0), states.shape[0],
+                                                       out.data_ptr(), _native.current_stream(states.device)), "pulse_qnet_forward")
+        return out
+
+    def get_actions(self, states):
+        """Player.py:242-253: epsilon-greedy actions for every row of `states` -> int64[n]."""
+        self._decay_epsilon()
+        states = self._rows(states)
+        actions = torch.empty(states.shape[0], dtype=torch.long, device=states.device)
+        self._calls += 1
+        net = self._net_struct(self.network)
+        _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), states.shape[0], None, 0,
+                                                   float(self.epsilon), self.seed & (2**64 - 1), (1 << 40) + self._calls,
+                                                   self.table_id0, actions.data_ptr(), None,
+                                                   _native.current_stream(states.device)), "pulse_qnet_act")
+        return actions
+
+    def act_into(self, states, curr_players, q_seat: int, actions, step_counter=None):
+        """`actions[mask] = self.get_actions(states[mask])` for mask = (curr_players == q_seat) (utils.py:113-119) as one
+        launch: rows of other seats are not touched, nothing is gathered, nothing syncs."""
+        self._decay_epsilon()
+        states = self._rows(states)
+        if actions.dtype != torch.int64 or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous int64 tensor (it is written in place)")
+        curr = curr_players if (curr_players.dtype == torch.int32 and curr_players.is_contiguous()) else curr_players.to(torch.int32).contiguous()
+        self._calls += 1
+        step = (1 << 40) + self._calls if step_counter is None else int(step_counter)
+        net = self._net_struct(self.network)
+        _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), states.shape[0],
+                                                   curr.data_ptr(), int(q_seat), float(self.epsilon), self.seed & (2**64 - 1), step,
+                                                   self.table_id0, actions.data_ptr(), None,
+                                                   _native.current_stream(states.device)), "pulse_qnet_act")
+        return actions
+
+    # ------------------------------------------------------------------ learning
+    def _after_update(self, loss, q_taken, rewards):
+        self.step_count += 1
+        if self.step_count % 1000 == 0:                                            # Player.py:281-287
+            print(f"Step {self.step_count} | Avg Loss: {float(loss):.2f} | Avg Q: {float(q_taken.mean()):.2f} | "
+                  f"Avg Reward: {float(rewards.mean()):.2f} | Epsilon: {self.epsilon:.4f}")
+        if self.step_count % self.update_freq == 0:                                # :289-290
+            self.target_network.load_state_dict(self.network.state_dict())
+
+    def train_step(self, states, actions, rewards, next_states, dones):
+        """Player.py:255-294, the reference's filtering semantics (boolean indexing: syncs with the host)."""
+        valid_mask = (states[:, 12] == 0) | (states[:, 12] == 2)                   # seat status ACTIVE or ALLIN (:261)
+        if not valid_mask.any():
+            return 0.0
+        states, actions, rewards = states[valid_mask], actions[valid_mask], rewards[valid_mask]
+        next_states, dones = next_states[valid_mask], dones[valid_mask]
+        q_taken = self.forward(states).gather(1, actions.unsqueeze(1)).squeeze(1)
+        with torch.no_grad():
+            next_q = self.target_network(next_states).max(dim=1).values
+            targets = rewards + self.gamma * next_q * (~dones).float()
+        loss = self.criterion(q_taken, targets)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
+        if self._lr_gate is not None:
+            self._lr_gate.fill_(self.lr)
+        self.optimizer.step()
+        self._after_update(loss, q_taken, rewards)
+        return loss
+
+    def train_step_masked(self, states, actions, rewards, next_states, dones, row_mask):
+        """The same update with the row filter (`row_mask & status in {ACTIVE, ALLIN}`) applied as 0/1 weights:
+        loss = sum w (q - target)^2 / max(sum w, 1).  No boolean indexing, no `.any()`: nothing syncs.  When no row
+        is valid the gradient is zero and the learning rate of this step is gated to zero on the device, so the
+        weights do not move (the reference returns before the optimizer; only AdamW's moment decay differs)."""
+        w = (row_mask & ((states[:, 12] == 0) | (states[:, 12] == 2))).to(torch.float32)
+        count = w.sum()
+        q_taken = self.forward(states).gather(1, actions.clamp(0, self.action_dim - 1).unsqueeze(1)).squeeze(1)
+        with torch.no_grad():
+            next_q = self.q_values(next_states, target=True).max(dim=1).values
+            targets = rewards + self.gamma * next_q * (~dones).float()
+        loss = (w * (q_taken - targets) ** 2).sum() / count.clamp(min=1.0)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
+        if self._lr_gate is None:
+            self._lr_gate = torch.zeros((), dtype=torch.float32, device=states.device)
+            for g in self.optimizer.param_groups:
+                g["lr"] = self._lr_gate                     # tensor lr: read on the device by the fused AdamW
+        self._lr_gate.copy_((count > 0).to(torch.float32) * self.lr)
+        self.optimizer.step()
+        self._after_update_masked()
+        return loss
+
+    def _after_update_masked(self):
+        self.step_count += 1
+        if self.step_count % self.update_freq == 0:
+            self.target_network.load_state_dict(self.network.state_dict())

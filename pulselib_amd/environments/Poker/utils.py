@@ -3,8 +3,8 @@ environments/Poker/utils.py (:80-87 PokerAgentType, :108-123 build_actions, :125
 load_gpu_agents, :173-183 get_rotated_agents), without its eval7 import.
 
 `build_actions` serves every scripted seat type with ONE launch of the policy kernel
-(pulse_poker_policy) instead of one boolean-mask round trip per type; Q-network seats keep the
-reference's masked call into the agent."""
+(pulse_poker_policy) instead of one boolean-mask round trip per type; a Q-network seat is served by the
+agent's fused `act_into` (qnetwork.py) when it has one, else by the reference's masked call into the agent."""
 from __future__ import annotations
 
 import ctypes as C
@@ -81,6 +81,11 @@ def build_actions(state, actions, curr_players, agents, agent_types, device, eps
         if NATIVE_TYPE.get(agent_type, _native.AGENT_EXTERNAL) == _native.AGENT_EXTERNAL:
             grouped.setdefault(agent_type, []).append(agent_idx)
     for agent_type, seat_indices in grouped.items():
+        agent = agents[seat_indices[0]]
+        if agent_type == PokerAgentType.QLEARNING and hasattr(agent, "act_into") and state.is_cuda:
+            for seat_idx in seat_indices:          # one fused launch per learner seat: no mask gather, no sync
+                agent.act_into(state, curr_players, seat_idx, actions)
+            continue
         mask = torch.zeros_like(curr_players, dtype=torch.bool)
         for seat_idx in seat_indices:
             mask |= curr_players == seat_idx
