@@ -87,14 +87,8 @@ class Runner:
         self.episode = 0
         self.global_step = 0           # Philox offset of the scripted policies
         self.steps_in_episode = 0
-        self.side = torch.cuda.Stream(device=device)
-        self.counts_dev = torch.zeros(2, dtype=torch.int64, device=device)
-        self.counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()
-        self.copy_events = [torch.cuda.Event(), torch.cuda.Event()]
-        self.counts_seen = [0, 0]      # cumulative done-counts already consumed per slot
-        self.pending = []              # chunk ids whose done-count copy is in flight
-        self._late_over = False
-        self.chunk = 0
+        from pulselib_amd.stoprule import LaggedDoneCount
+        self.done_count = LaggedDoneCount(device, self.N, TERMINATION_THRESHOLD)
         self.episode_stats = torch.zeros(2, dtype=torch.float64, device=device)
         self.new_episode()
 
@@ -104,47 +98,7 @@ class Runner:
         self.env.reset(options={"rotation": rotation, "active_players": int(A), "q_agent_seat": q_seat})
         self.episode += 1
         self.steps_in_episode = 0
-        while self.pending:            # keep the cumulative counters consistent across episodes
-            self.copy_events[self.pending[0] & 1].synchronize()
-            self._pop_count()
-        self._late_over = False
-
-    def _count_done_async(self):
-        """#done tables of the current state -> pinned host memory on the side stream (no host sync)."""
-        env, slot = self.env, self.chunk & 1
-        while len(self.pending) >= 2:                      # bounded run-ahead: never reuse a slot still in flight
-            self.copy_events[self.pending[0] & 1].synchronize()
-            self._late_over = self._late_over or self._pop_count()
-        # counts_dev[slot] is cumulative (pulse_poker_stats adds): no memset kernel in the loop
-        env._lib.pulse_poker_stats(env.is_done.data_ptr(), None, None, self.N, self.counts_dev[slot:].data_ptr(), None,
-                                   torch.cuda.current_stream(self.device).cuda_stream)
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            self.counts_host[slot:slot + 1].copy_(self.counts_dev[slot:slot + 1], non_blocking=True)
-            self.copy_events[slot].record(self.side)
-        self.pending.append(self.chunk)
-
-    def _episode_over(self, blocking):
-        """Stop rule of trainGPU.py:27-33 on the newest done-count that has reached the host."""
-        over, self._late_over = self._late_over, False
-        while self.pending:
-            c = self.pending[0]
-            ev = self.copy_events[c & 1]
-            if blocking:
-                ev.synchronize()
-            elif not ev.query():
-                break
-            over = over or self._pop_count()
-        return over
-
-    def _pop_count(self):
-        c = self.pending.pop(0)
-        total = int(self.counts_host[c & 1].item())
-        n_done = total - self.counts_seen[c & 1]
-        self.counts_seen[c & 1] = total
-        return n_done > TERMINATION_THRESHOLD * self.N
+        self.done_count.drain()
 
     def run_steps(self, k, time_every=0):
         """Run exactly k counted steps (episodes roll over inside)."""
@@ -162,9 +116,8 @@ class Runner:
             done += n
             # trainGPU.py:99: the check happens at idx % 5 == 0, i.e. after steps 1, 6, 11, ...; chunks of five
             # steps check after steps 5, 10, ... -- same cadence, first check four steps later.
-            self._count_done_async()
-            self.chunk += 1
-            if self._episode_over(blocking=self.args.stop_rule == "sync") or self.steps_in_episode >= self.args.max_episode_steps:
+            self.done_count.submit(env.is_done)      # stop rule without a host sync (pulselib_amd/stoprule.py)
+            if self.done_count.over(blocking=self.args.stop_rule == "sync") or self.steps_in_episode >= self.args.max_episode_steps:
                 self.end_episode()
         return done
 

@@ -283,6 +283,62 @@ def qnet_act(q: np.ndarray, seat_idx, q_seat: int, epsilon: float, seed: int, st
     return actions
 
 
+def qnet_param_count(state_dim: int, n_actions: int) -> int:
+    return 128 * state_dim + 128 + 128 * 128 + 128 + 64 * 128 + 64 + 32 * 64 + 32 + 32 * n_actions + n_actions
+
+
+def qnet_split(flat: np.ndarray, state_dim: int, n_actions: int):
+    """flat parameter vector (w1,b1,...,w5,b5) -> ([w1..w5], [b1..b5]) views."""
+    dims = [state_dim, 128, 128, 64, 32, n_actions]
+    ws, bs, o = [], [], 0
+    for l in range(5):
+        n = dims[l + 1] * dims[l]
+        ws.append(flat[o:o + n].reshape(dims[l + 1], dims[l])); o += n
+        bs.append(flat[o:o + dims[l + 1]]); o += dims[l + 1]
+    assert o == flat.size
+    return ws, bs
+
+
+def qnet_train_grads(params: np.ndarray, target: np.ndarray, states, actions, rewards, next_states, dones, row_mask,
+                     gamma: float, drop_p: float, seed: int, step: int, table_id0: int):
+    """oracle/qnet_oracle.c: oracle_qnet_train_grads -> (grad_sum flat fp32, row count, sum of squared TD errors)."""
+    states = np.ascontiguousarray(states, dtype=np.float32)
+    next_states = np.ascontiguousarray(next_states, dtype=np.float32)
+    n, k = states.shape
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    target = np.ascontiguousarray(target, dtype=np.float32)
+    n_actions = (params.size - (128 * k + 128 + 128 * 128 + 128 + 64 * 128 + 64 + 32 * 64 + 32)) // 33
+    ws, bs, aw, ab = _qnet_ptrs(*qnet_split(params, k, n_actions))
+    tws, tbs, atw, atb = _qnet_ptrs(*qnet_split(target, k, n_actions))
+    actions = np.ascontiguousarray(actions, dtype=np.int64)
+    rewards = np.ascontiguousarray(rewards, dtype=np.float32)
+    dones = np.ascontiguousarray(dones, dtype=np.uint8)
+    rm = None if row_mask is None else np.ascontiguousarray(row_mask, dtype=np.uint8)
+    grad = np.zeros(params.size, dtype=np.float32)
+    sq = C.c_float(0)
+    fn = lib().oracle_qnet_train_grads
+    fn.restype = C.c_int
+    cnt = fn(C.c_int(k), C.c_int(n_actions), aw, ab, atw, atb, states.ctypes.data_as(C.c_void_p), C.c_long(k),
+             actions.ctypes.data_as(C.c_void_p), rewards.ctypes.data_as(C.c_void_p), next_states.ctypes.data_as(C.c_void_p),
+             C.c_long(k), dones.ctypes.data_as(C.c_void_p), None if rm is None else rm.ctypes.data_as(C.c_void_p), C.c_int(n),
+             C.c_float(gamma), C.c_float(drop_p), C.c_uint64(seed), C.c_uint64(step), C.c_uint64(table_id0),
+             grad.ctypes.data_as(C.c_void_p), C.byref(sq))
+    return grad, int(cnt), float(sq.value)
+
+
+def qnet_adamw(params, target, grad, m, v, count: int, t: int, lr, wd, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=1.0,
+               update_freq=0) -> float:
+    """oracle/qnet_oracle.c: oracle_qnet_adamw; params/target/m/v (contiguous fp32) are updated in place."""
+    for a in (params, target, grad, m, v):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    fn = lib().oracle_qnet_adamw
+    fn.restype = C.c_float
+    return float(fn(C.c_int(params.size), params.ctypes.data_as(C.c_void_p), target.ctypes.data_as(C.c_void_p),
+                    grad.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.c_int(count),
+                    C.c_long(t), C.c_float(lr), C.c_float(wd), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                    C.c_float(max_norm), C.c_int(update_freq)))
+
+
 def philox4x32(seed: int, subseq: int, offset: int) -> np.ndarray:
     out = np.zeros(4, dtype=np.uint32)
     lib().oracle_philox4x32(C.c_uint64(seed), C.c_uint64(subseq), C.c_uint64(offset), out.ctypes.data_as(C.c_void_p))

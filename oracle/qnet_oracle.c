@@ -59,3 +59,109 @@ void oracle_qnet_act(int n_actions, const float* q, int n_rows, const int32_t* s
         actions[r] = explore ? (int64_t)(((uint64_t)rnd[1] * (uint64_t)n_actions) >> 32) : (int64_t)arg;   /* :249-250 */
     }
 }
+
+/* ---- train_step (Player.py:255-294), scalar ------------------------------------------------------------------
+ * Row filter: row_mask[r] (NULL = all) and states[r][12] in {0, 2} (:261).  Forward in train mode: Dropout(.1) after
+ * the 2nd and 3rd GELU (:194,:197) with the framework's own draw definition (torch's generator is not reproducible
+ * across devices): hidden unit u (0..127 = layer 2, 128..191 = layer 3) of table g drops when the 16-bit uniform
+ *   word (u % 8) / 2, half u % 2 of Philox4x32-10(seed ^ 0xD50F0D50F0, g, 32 * step + u / 8)
+ * is below (uint32)(p * 65536); kept units are scaled by 1 / (1 - p).  Target r + gamma * max Q_target(s') * !done
+ * (:275-277).  Outputs: grad = d/dtheta of sum_rows (q[a] - target)^2 (NOT yet divided by the row count), flat layout
+ * w1,b1,...,w5,b5; returns the row count, *sum_sq the summed squared TD error. */
+static float gelu_grad_exact(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+static int drop_keep(uint64_t seed, uint64_t g, uint64_t step, int u, uint32_t thr) {
+    uint32_t w[4];
+    oracle_philox4x32(seed ^ 0xD50F0D50F0ull, g, step * 32 + (uint64_t)(u / 8), w);
+    const uint32_t word = w[(u % 8) / 2];
+    const uint32_t u16 = (u % 2) ? (word >> 16) : (word & 0xFFFFu);
+    return u16 >= thr;
+}
+
+int oracle_qnet_train_grads(int state_dim, int n_actions, const float* const* w, const float* const* b,
+                            const float* const* tw, const float* const* tb, const float* states, long stride,
+                            const int64_t* actions, const float* rewards, const float* next_states, long next_stride,
+                            const uint8_t* dones, const uint8_t* row_mask, int n_rows, float gamma, float drop_p,
+                            uint64_t seed, uint64_t step, uint64_t table_id0, float* grad, float* sum_sq) {
+    const int dims[6] = {state_dim, 128, 128, 64, 32, n_actions};
+    size_t off_w[5], off_b[5], o = 0;
+    for (int l = 0; l < 5; l++) { off_w[l] = o; o += (size_t)dims[l + 1] * dims[l]; off_b[l] = o; o += dims[l + 1]; }
+    for (size_t i = 0; i < o; i++) grad[i] = 0.0f;
+    const uint32_t thr = (uint32_t)(drop_p * 65536.0f);
+    const float scale = 1.0f / (1.0f - drop_p);
+    int count = 0; double sq = 0.0;
+    for (int r = 0; r < n_rows; r++) {
+        const float* x = states + (size_t)r * stride;
+        if (row_mask && !row_mask[r]) continue;
+        if (!(x[12] == 0.0f || x[12] == 2.0f)) continue;
+        const uint64_t g = table_id0 + (uint64_t)r;
+        float a[6][128], gd[6][128];            /* a[l] = output of layer l (a[0] = input), gd[l] = local derivative */
+        for (int k = 0; k < state_dim; k++) a[0][k] = x[k];
+        for (int l = 0; l < 5; l++) {
+            for (int u = 0; u < dims[l + 1]; u++) {
+                float z = 0.0f;
+                for (int k = 0; k < dims[l]; k++) z += w[l][(size_t)u * dims[l] + k] * a[l][k];
+                z += b[l][u];
+                if (l == 4) { a[5][u] = z; continue; }
+                float m = 1.0f;
+                if (l == 1) m = drop_keep(seed, g, step, u, thr) ? scale : 0.0f;
+                if (l == 2) m = drop_keep(seed, g, step, 128 + u, thr) ? scale : 0.0f;
+                a[l + 1][u] = gelu_exact(z) * m;
+                gd[l + 1][u] = gelu_grad_exact(z) * m;
+            }
+        }
+        float qn[32], best = -INFINITY;
+        oracle_qnet_forward(state_dim, n_actions, tw, tb, next_states + (size_t)r * next_stride, next_stride, 1, qn);
+        for (int u = 0; u < n_actions; u++) if (qn[u] > best) best = qn[u];
+        const float target = rewards[r] + gamma * best * (dones[r] ? 0.0f : 1.0f);
+        const int act = (int)actions[r];
+        const float td = a[5][act] - target;
+        count++; sq += (double)td * td;
+        float d[128], dprev[128];
+        for (int u = 0; u < n_actions; u++) d[u] = (u == act) ? 2.0f * td : 0.0f;
+        for (int l = 4; l >= 0; l--) {
+            for (int u = 0; u < dims[l + 1]; u++) {
+                grad[off_b[l] + u] += d[u];
+                for (int k = 0; k < dims[l]; k++) grad[off_w[l] + (size_t)u * dims[l] + k] += d[u] * a[l][k];
+            }
+            if (l == 0) break;
+            for (int k = 0; k < dims[l]; k++) {
+                float s = 0.0f;
+                for (int u = 0; u < dims[l + 1]; u++) s += w[l][(size_t)u * dims[l] + k] * d[u];
+                dprev[k] = s * gd[l][k];
+            }
+            for (int k = 0; k < dims[l]; k++) d[k] = dprev[k];
+        }
+    }
+    *sum_sq = (float)sq;
+    return count;
+}
+
+/* gradient mean, clip_grad_norm_(max_norm) (:280), torch.optim.AdamW step (:281), target sync (:289-290); t = the new
+ * step number (1-based).  count == 0: nothing changes (:262).  Returns the gradient norm before clipping. */
+float oracle_qnet_adamw(int n_params, float* params, float* target, const float* grad, float* m, float* v, int count,
+                        long t, float lr, float wd, float beta1, float beta2, float eps, float max_norm, int update_freq) {
+    if (count <= 0) return 0.0f;
+    const float inv = 1.0f / (float)count;
+    double ss = 0.0;
+    for (int i = 0; i < n_params; i++) { const float g = grad[i] * inv; ss += (double)g * g; }
+    const float norm = (float)sqrt(ss);
+    float coef = max_norm / (norm + 1e-6f);
+    if (coef > 1.0f) coef = 1.0f;
+    coef *= inv;
+    const float bc1 = 1.0f - powf(beta1, (float)t), bc2 = 1.0f - powf(beta2, (float)t);
+    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    for (int i = 0; i < n_params; i++) {
+        const float g = grad[i] * coef;
+        float p = params[i] * (1.0f - lr * wd);
+        m[i] = beta1 * m[i] + (1.0f - beta1) * g;
+        v[i] = beta2 * v[i] + (1.0f - beta2) * g * g;
+        p -= step_size * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+        params[i] = p;
+        if (update_freq > 0 && t % update_freq == 0) target[i] = p;
+    }
+    return norm;
+}

@@ -57,6 +57,14 @@ class QNet(C.Structure):
         "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "w5", "b5")]
 
 
+class QNetTrain(C.Structure):
+    _fields_ = [("net", QNet), ("target", QNet)] + [(n, C.c_void_p) for n in (
+        "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report", "row_list")] + [
+        ("row_list_capacity", C.c_int32), ("reserved1", C.c_int32)] + [(n, C.c_float) for n in (
+            "lr", "weight_decay", "beta1", "beta2", "eps", "max_grad_norm", "gamma", "dropout_p")] + [
+        ("update_freq", C.c_int32), ("reserved0", C.c_int32)]
+
+
 class QTable(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("capacity", C.c_uint64), ("region_slots", C.c_uint64)]
 
@@ -94,6 +102,8 @@ SYMBOLS = {
     "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
     "pulse_qnet_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P]),
+    "pulse_qnet_param_count": (C.c_int, [_I32, _I32]),
+    "pulse_qnet_train_step": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I32, _U64, _U64, _U64, _P]),
 }
 
 

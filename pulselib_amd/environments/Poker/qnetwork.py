@@ -6,11 +6,12 @@ What is native here:
   * action selection -- `get_actions`, and the fused masked form `act_into` used by `build_actions` -- is one
     MFMA kernel (csrc/qnet.hip) reading the module's own weight tensors; no mask gather / scatter, no
     host sync, draws keyed by (seed, global table id, step) like the scripted opponents';
-  * `train_step_masked`, the sync-free form of `train_step`: the reference filters rows with boolean indexing
-    (a device->host sync per mask); here every row goes through with a 0/1 weight, so the loss, the clipped
-    gradient and the AdamW update are those of the filtered batch while nothing waits on the host.
-`train_step` itself keeps the reference's filtering semantics verbatim (Player.py:255-294); both run on
-PyTorch-ROCm autograd (the learner's GEMMs are PyTorch plumbing for now)."""
+  * `train_step_native`: the whole update -- row filter, forward in train mode, TD target, backward, gradient
+    clipping, AdamW, target sync -- as three launches of csrc/qnet.hip with no host sync (the reference's boolean
+    indexing costs a device->host sync per mask);
+  * `train_step_masked`: the same sync-free contract on PyTorch-ROCm autograd (every row goes through with a 0/1
+    weight), kept as the torch cross-check of the native path.
+`train_step` itself keeps the reference's filtering semantics verbatim (Player.py:255-294) on PyTorch autograd."""
 from __future__ import annotations
 
 import copy
@@ -62,6 +63,9 @@ class PokerQNetwork(nn.Module):
         self.step_count = 0
         self.criterion = nn.MSELoss()
         self.to(device)
+        self._native = None
+        if torch.device(device).type == "cuda":
+            self._flatten()                   # parameters become views of one flat buffer per network (pulse_env.h: PulseQNetTrain)
         self.optimizer = self.configure_optimizers()
         # Philox keys of the exploration draws (act_into takes the env step counter; get_actions counts its calls)
         self.seed, self.table_id0 = int(seed), int(table_id0)
@@ -139,6 +143,87 @@ class PokerQNetwork(nn.Module):
                                                    self.table_id0, actions.data_ptr(), None,
                                                    _native.current_stream(states.device)), "pulse_qnet_act")
         return actions
+
+    # ------------------------------------------------------------------ native learning (csrc/qnet.hip)
+    def _flatten(self):
+        flats = []
+        for net in (self.network, self.target_network):
+            n = sum(p.numel() for li in LINEAR_INDICES for p in (net[li].weight, net[li].bias))
+            flat = torch.empty(n, dtype=torch.float32, device=self.device)
+            o = 0
+            for li in LINEAR_INDICES:
+                for p in (net[li].weight, net[li].bias):
+                    view = flat[o:o + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                    o += p.numel()
+            flats.append(flat)
+        self._flat, self._flat_target = flats
+
+    def _native_state(self, n_rows: int):
+        nat = self._native
+        if nat is None or nat["rows"].numel() < n_rows + 1:
+            if getattr(self, "_flat", None) is None:
+                raise RuntimeError("PokerQNetwork: native training runs on the MI355X only (construct it on a cuda device)")
+            dev, n = self._flat.device, self._flat.numel()
+            assert n == _native.lib().pulse_qnet_param_count(self.state_dim, self.action_dim)
+            old = nat or {}
+            nat = self._native = {
+                "grad": old.get("grad", torch.zeros(n, dtype=torch.float32, device=dev)),
+                "m": old.get("m", torch.zeros(n, dtype=torch.float32, device=dev)),
+                "v": old.get("v", torch.zeros(n, dtype=torch.float32, device=dev)),
+                "step": old.get("step", torch.zeros(1, dtype=torch.int64, device=dev)),
+                "stats": old.get("stats", torch.zeros(2, dtype=torch.float32, device=dev)),
+                "report": old.get("report", torch.zeros(4, dtype=torch.float32, device=dev)),
+                "rows": torch.zeros(n_rows + 1, dtype=torch.int32, device=dev),
+            }
+        t = _native.QNetTrain()
+        t.net, t.target = self._net_struct(self.network), self._net_struct(self.target_network)
+        t.params, t.target_params = self._flat.data_ptr(), self._flat_target.data_ptr()
+        t.grad, t.exp_avg, t.exp_avg_sq = nat["grad"].data_ptr(), nat["m"].data_ptr(), nat["v"].data_ptr()
+        t.step, t.stats, t.report = nat["step"].data_ptr(), nat["stats"].data_ptr(), nat["report"].data_ptr()
+        t.row_list, t.row_list_capacity = nat["rows"].data_ptr(), nat["rows"].numel() - 1
+        t.lr, t.weight_decay, t.beta1, t.beta2, t.eps = self.lr, self.wd, 0.9, 0.999, 1e-8       # torch.optim.AdamW defaults (:296)
+        t.max_grad_norm, t.gamma = 1.0, float(self.gamma)                                      # clip_grad_norm_ (:280)
+        t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
+        t.update_freq = int(self.update_freq)
+        return t
+
+    def train_step_native(self, states, actions, rewards, next_states, dones, row_mask=None, step_counter=None):
+        """train_step (Player.py:255-294) as three launches on the env's stream and no host sync: row filter
+        (row_mask & seat status ACTIVE/ALLIN) -> forward + TD target + backward on the matrix cores -> gradient mean,
+        clip_grad_norm_, AdamW, target sync every update_freq optimizer steps.  Returns the device tensor
+        [rows trained on, MSE loss, gradient norm before clipping, 0] of this call (read it later, or never).
+        Moments live in this path's own buffers (not in self.optimizer, which serves the torch train_step)."""
+        states, next_states = self._rows(states), self._rows(next_states)
+        n = states.shape[0]
+        t = self._native_state(n)
+
+        def u8(x):
+            if x is None:
+                return None
+            if x.dtype == torch.bool:
+                x = x.view(torch.uint8)
+            if x.dtype != torch.uint8 or not x.is_contiguous():
+                x = x.to(torch.uint8).contiguous()
+            return x
+        dones8, mask8 = u8(dones), u8(row_mask)
+        if actions.dtype != torch.int64 or not actions.is_contiguous():
+            actions = actions.to(torch.int64).contiguous()
+        if rewards.dtype != torch.float32 or not rewards.is_contiguous():
+            rewards = rewards.to(torch.float32).contiguous()
+        self._calls += 1
+        step = (1 << 41) + self._calls if step_counter is None else int(step_counter)
+        _native.check(_native.lib().pulse_qnet_train_step(
+            C.byref(t), states.data_ptr(), states.stride(0), actions.data_ptr(), rewards.data_ptr(), next_states.data_ptr(),
+            next_states.stride(0), dones8.data_ptr(), None if mask8 is None else mask8.data_ptr(), n, self.seed & (2**64 - 1), step,
+            self.table_id0, _native.current_stream(states.device)), "pulse_qnet_train_step")
+        self.step_count += 1             # calls; the optimizer-step count (calls with at least one valid row) is native_steps()
+        return self._native["report"]
+
+    def native_steps(self) -> int:
+        """Optimizer steps taken by train_step_native (device counter; reading it syncs)."""
+        return 0 if self._native is None else int(self._native["step"].item())
 
     # ------------------------------------------------------------------ learning
     def _after_update(self, loss, q_taken, rewards):

@@ -91,6 +91,93 @@ def train_agent(env, agents, agent_types, episodes, n_games, device, results_dir
     return summary
 
 
+def train_agent_fused(env, agents, agent_types, episodes, n_games, device, results_dir=None, config=None, plotter=None,
+                      benchmarker=None, max_episode_steps=None, reduce_stats=True, stop_rule="lagged", host_seed=0,
+                      step_hook=None, learner="native"):
+    """train_agent with nothing in the step waiting on the host: the loop contract above (rotation, masks evaluated
+    before `terminated |= dones`, stop cadence, step accounting) on four launches-groups per step --
+      learner's actions (pulse_qnet_act, masked by seat) -> scripted opponents + env step (pulse_poker_policy_step) ->
+      the learner's update (`learner="native"`: train_step_native, three HIP launches; `"torch"`: train_step_masked on
+      PyTorch autograd) -> every 5th step the lagged done-count.
+    `active_players` is drawn from a host RNG (the reference reads a device randint back, PokerGPU.py:76-77) and the
+    stop rule is decided on the newest count that already reached the host (stoprule.py); `stop_rule="sync"`
+    restores the reference's blocking check.  Needs a learner with `act_into` / `train_step_masked` (qnetwork.py)."""
+    import random
+
+    from ..environments.Poker.utils import native_types
+    from ..stoprule import LaggedDoneCount
+    config = config or {}
+    q_agent_idx = agent_types.index(PokerAgentType.QLEARNING)
+    q_agent = agents[q_agent_idx]
+    if not (hasattr(q_agent, "act_into") and hasattr(q_agent, "train_step_masked") and hasattr(q_agent, "train_step_native")):
+        raise TypeError("train_agent_fused needs a learner with act_into / train_step_native (PokerQNetwork)")
+    learn = q_agent.train_step_native if learner == "native" else q_agent.train_step_masked
+    host_rng = random.Random(host_seed)
+    done_count = LaggedDoneCount(device, n_games, TERMINATION_THRESHOLD)
+    actions = torch.zeros(n_games, dtype=torch.long, device=device)
+    state_before = torch.empty((n_games, env.obs_size), dtype=torch.float32, device=device)
+    terminated = torch.zeros(n_games, dtype=torch.bool, device=device)
+    episode_reward = torch.zeros((), dtype=torch.float64, device=device)
+    stats = EpisodeStats(device)
+    total_steps, global_step = 0, 0
+    scores, reward_scores = [], []
+    start_time = time.time()
+    for episode in range(episodes):
+        _, rotated_types, q_seat, rotations = get_rotated_agents(agents, agent_types, episode_idx=episode, q_agent_idx=q_agent_idx)
+        native = native_types(rotated_types)                     # the learner's seat is EXTERNAL: its action is taken as given
+        A = host_rng.randint(2, env.n_players)
+        state, info = env.reset(options={"rotation": rotations, "active_players": int(A), "q_agent_seat": q_seat})
+        initial_stacks = info["stacks"][:, q_seat].clone()
+        terminated.zero_()
+        episode_reward.zero_()
+        done_count.drain()
+        idx = 0
+        while True:
+            seat_idx = info["seat_idx"]
+            q_mask = seat_idx == q_seat
+            active_games = q_mask & ~terminated                                       # trainGPU.py:85, before the step
+            state_before.copy_(state)                                                 # the env reuses its obs buffer
+            q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step)
+            next_state, rewards, dones, _, info = env.policy_step(native, actions, global_step)
+            terminated |= dones                                                       # :86
+            learn(state_before, actions, rewards, next_state, dones, active_games)
+            episode_reward += (rewards * active_games).sum()                          # :96
+            if step_hook is not None:
+                step_hook(episode, idx, state_before, actions, rewards, next_state, dones, active_games)
+            state = next_state
+            global_step += 1
+            if idx % CHECK_INTERVAL == 0:                                             # :27-33 cadence
+                done_count.submit(terminated)
+                if done_count.over(blocking=stop_rule == "sync"):
+                    break
+            idx += 1
+            if max_episode_steps is not None and idx >= max_episode_steps:
+                break
+        final_stacks = info["stacks"][:, q_seat]
+        stats.set(terminated.sum(), episode_reward, (final_stacks - initial_stacks).sum())
+        totals = (stats.all_reduce_async() if reduce_stats else stats).wait()
+        host = totals.cpu()                                                           # one read-back per episode
+        reward_scores.append(float(host[1]))
+        scores.append(float(host[2]))
+        total_steps += n_games * idx                                                  # :108
+
+    torch.cuda.synchronize(device)
+    end_time = time.time()
+    elapsed = end_time - start_time
+    summary = {"env": config.get("ENV_ID", "Pulse-Poker-GPU-v1"), "total_steps": total_steps, "start_time": start_time,
+               "end_time": end_time, "total_training_seconds": elapsed, "sps": total_steps / elapsed if elapsed > 0 else 0.0,
+               "episode_rewards": reward_scores, "episode_profits": scores, "config": dict(config), "env_step_calls": global_step}
+    if plotter is not None and results_dir is not None:
+        plotter.plot_learning_curve(scores=reward_scores, file_path=str(Path(results_dir) / "rewards_learning_curve"), window_size=10,
+                                    title="Poker Q-Learning - Total Reward per Episode Batch")
+        plotter.plot_learning_curve(scores=scores, file_path=str(Path(results_dir) / "total_chips_curve"), window_size=10,
+                                    title="Poker Q-Learning - Total Chip Profit per Episode Batch")
+    if benchmarker is not None:
+        benchmarker.create_benchmark_file(env_name=summary["env"], episodes_return=reward_scores, start_time=start_time,
+                                          end_time=end_time, total_steps=total_steps, config=config)
+    return summary
+
+
 class SimpleQNetwork(torch.nn.Module):
     """Minimal learner with the interface the driver needs (the reference's PokerQNetwork,
     environments/Poker/Player.py:178-298, is the real one and runs unchanged on PyTorch-ROCm)."""

@@ -1,0 +1,62 @@
+"""Trainer-loop env-steps/sec (SURVEY.md 8d second line, 8f.1): the Poker roll-out WITH the learner in the loop --
+PokerQNetwork acting (MFMA kernel) and learning (train_step_masked, PyTorch-ROCm autograd) every step -- counted the
+reference's way (n_tables x steps per episode / wall time, scripts/Poker/trainGPU.py:108,116).
+
+    python tools/bench_trainer.py [--tables 65536] [--episodes 20] [--warmup 3] [--loop fused|reference]
+
+`--loop reference` runs train_agent, the loop with the reference's host syncs (boolean-mask indexing, blocking stop
+rule), on the same kernels for comparison.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+AGENTS = ["tight_aggressive", "heuristic_hands", "heuristic_hands", "loose_passive", "tight_aggressive",
+          "random", "loose_passive", "small_ball", "tight_aggressive"]   # reference config/pokerGPU.yaml:5-14
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tables", type=int, default=65536)
+    ap.add_argument("--episodes", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--loop", choices=["fused", "reference"], default="fused")
+    ap.add_argument("--learner", choices=["native", "torch"], default="native", help="fused loop only")
+    ap.add_argument("--max-episode-steps", type=int, default=40)
+    args = ap.parse_args()
+    from pulselib_amd.environments.Poker import PokerGPU, PokerQNetwork, load_gpu_agents
+    from pulselib_amd.environments.Poker.utils import PokerAgentType
+    from pulselib_amd.scripts.trainGPU import train_agent, train_agent_fused
+    device = torch.device("cuda", 0)
+    agents, types = load_gpu_agents(device, 9, AGENTS, 100, 13)
+    q = PokerQNetwork(None, device, gamma=.95, update_freq=20, state_dim=40, action_dim=13, learning_rate=2e-4, weight_decay=1e-5,
+                      seed=20260401)
+    agents.insert(0, q)
+    types.insert(0, PokerAgentType.QLEARNING)
+    env = PokerGPU(device=device, agents=agents, n_players=10, max_players=10, n_games=args.tables, starting_bbs=100, max_bbs=1000,
+                   w1=.5, w2=.3, K=100, alpha=50, seed=20260401)
+    run = train_agent_fused if args.loop == "fused" else train_agent
+    kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=False)
+    if args.loop == "fused":
+        kw["learner"] = args.learner
+    run(env, agents, types, args.warmup, args.tables, device, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(env, agents, types, args.episodes, args.tables, device, **kw)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    steps = out["total_steps"] // args.tables
+    print(json.dumps({"metric": "trainer-loop env-steps/sec, Poker batched tables (learner acting and learning every step)",
+                      "value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "n_gpus": 1, "loop": args.loop, "learner": args.learner if args.loop == "fused" else "torch",
+                      "tables": args.tables, "episodes": args.episodes, "step_calls_counted": steps,
+                      "ms_per_step": elapsed / max(steps, 1) * 1e3, "learner_calls": q.step_count,
+                      "mean_episode_reward": sum(out["episode_rewards"]) / max(len(out["episode_rewards"]), 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
