@@ -238,13 +238,12 @@ int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride
                    const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
                    uint64_t table_id0, int64_t* actions, float* q_out, void* stream);
 
-/* PokerQNetwork.train_step (Player.py:255-294) as two launches: forward (train mode) + TD target + backward on the
- * matrix cores, then gradient mean / clip_grad_norm_ / AdamW / target sync.  The network and its target each live in
+/* PokerQNetwork.train_step (Player.py:255-294) as two launches: row filter + TD target + forward (train mode) +
+ * backward on the matrix cores, then gradient mean / clip_grad_norm_ / AdamW / target sync.  The network and its target each live in
  * ONE flat fp32 buffer of pulse_qnet_param_count() floats laid out w1,b1,w2,b2,w3,b3,w4,b4,w5,b5 (torch layouts);
  * `net` / `target` hold the ten views.  grad, exp_avg, exp_avg_sq: flat buffers of the same length, zero before the
  * first call (the call leaves grad zeroed again).  step: device int64 optimizer step count (bias correction, target
- * sync every update_freq steps).  stats: device fp32[2] scratch, zero before the first call.  row_list: scratch for
- * the compacted ids of the rows that pass the filter (n_rows <= row_list_capacity).  report: device
+ * sync every update_freq steps).  stats: device fp32[2] scratch, zero before the first call.  report: device
  * fp32[4] out: [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping.
  * Row filter: row_mask[r] != 0 (NULL: all) and states[r][12] in {0, 2} (:261); if no row passes, nothing changes (:262).
  * Dropout(.1) after the 2nd and 3rd GELU draws 16-bit uniforms from Philox4x32-10(seed ^ 0xD50F0D50F0, table_id0 + r,
@@ -255,8 +254,6 @@ typedef struct PulseQNetTrain {
     float *params, *target_params, *grad, *exp_avg, *exp_avg_sq;
     int64_t* step;
     float *stats, *report;
-    int32_t* row_list;              /* device int32[1 + row_list_capacity] scratch, row_list[0] zero before the first call */
-    int32_t row_list_capacity, reserved1;
     float lr, weight_decay, beta1, beta2, eps, max_grad_norm, gamma, dropout_p;
     int32_t update_freq, reserved0;
 } PulseQNetTrain;

@@ -59,8 +59,7 @@ class QNet(C.Structure):
 
 class QNetTrain(C.Structure):
     _fields_ = [("net", QNet), ("target", QNet)] + [(n, C.c_void_p) for n in (
-        "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report", "row_list")] + [
-        ("row_list_capacity", C.c_int32), ("reserved1", C.c_int32)] + [(n, C.c_float) for n in (
+        "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report")] + [(n, C.c_float) for n in (
             "lr", "weight_decay", "beta1", "beta2", "eps", "max_grad_norm", "gamma", "dropout_p")] + [
         ("update_freq", C.c_int32), ("reserved0", C.c_int32)]
 

@@ -7,7 +7,7 @@ What is native here:
     MFMA kernel (csrc/qnet.hip) reading the module's own weight tensors; no mask gather / scatter, no
     host sync, draws keyed by (seed, global table id, step) like the scripted opponents';
   * `train_step_native`: the whole update -- row filter, forward in train mode, TD target, backward, gradient
-    clipping, AdamW, target sync -- as three launches of csrc/qnet.hip with no host sync (the reference's boolean
+    clipping, AdamW, target sync -- as two launches of csrc/qnet.hip with no host sync (the reference's boolean
     indexing costs a device->host sync per mask);
   * `train_step_masked`: the same sync-free contract on PyTorch-ROCm autograd (every row goes through with a 0/1
     weight), kept as the torch cross-check of the native path.
@@ -160,29 +160,26 @@ class PokerQNetwork(nn.Module):
             flats.append(flat)
         self._flat, self._flat_target = flats
 
-    def _native_state(self, n_rows: int):
+    def _native_state(self):
         nat = self._native
-        if nat is None or nat["rows"].numel() < n_rows + 1:
+        if nat is None:
             if getattr(self, "_flat", None) is None:
                 raise RuntimeError("PokerQNetwork: native training runs on the MI355X only (construct it on a cuda device)")
             dev, n = self._flat.device, self._flat.numel()
             assert n == _native.lib().pulse_qnet_param_count(self.state_dim, self.action_dim)
-            old = nat or {}
             nat = self._native = {
-                "grad": old.get("grad", torch.zeros(n, dtype=torch.float32, device=dev)),
-                "m": old.get("m", torch.zeros(n, dtype=torch.float32, device=dev)),
-                "v": old.get("v", torch.zeros(n, dtype=torch.float32, device=dev)),
-                "step": old.get("step", torch.zeros(1, dtype=torch.int64, device=dev)),
-                "stats": old.get("stats", torch.zeros(2, dtype=torch.float32, device=dev)),
-                "report": old.get("report", torch.zeros(4, dtype=torch.float32, device=dev)),
-                "rows": torch.zeros(n_rows + 1, dtype=torch.int32, device=dev),
+                "grad": torch.zeros(n, dtype=torch.float32, device=dev),
+                "m": torch.zeros(n, dtype=torch.float32, device=dev),
+                "v": torch.zeros(n, dtype=torch.float32, device=dev),
+                "step": torch.zeros(1, dtype=torch.int64, device=dev),
+                "stats": torch.zeros(2, dtype=torch.float32, device=dev),
+                "report": torch.zeros(4, dtype=torch.float32, device=dev),
             }
         t = _native.QNetTrain()
         t.net, t.target = self._net_struct(self.network), self._net_struct(self.target_network)
         t.params, t.target_params = self._flat.data_ptr(), self._flat_target.data_ptr()
         t.grad, t.exp_avg, t.exp_avg_sq = nat["grad"].data_ptr(), nat["m"].data_ptr(), nat["v"].data_ptr()
         t.step, t.stats, t.report = nat["step"].data_ptr(), nat["stats"].data_ptr(), nat["report"].data_ptr()
-        t.row_list, t.row_list_capacity = nat["rows"].data_ptr(), nat["rows"].numel() - 1
         t.lr, t.weight_decay, t.beta1, t.beta2, t.eps = self.lr, self.wd, 0.9, 0.999, 1e-8       # torch.optim.AdamW defaults (:296)
         t.max_grad_norm, t.gamma = 1.0, float(self.gamma)                                      # clip_grad_norm_ (:280)
         t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
@@ -190,14 +187,14 @@ class PokerQNetwork(nn.Module):
         return t
 
     def train_step_native(self, states, actions, rewards, next_states, dones, row_mask=None, step_counter=None):
-        """train_step (Player.py:255-294) as three launches on the env's stream and no host sync: row filter
-        (row_mask & seat status ACTIVE/ALLIN) -> forward + TD target + backward on the matrix cores -> gradient mean,
+        """train_step (Player.py:255-294) as two launches on the env's stream and no host sync: row filter
+        (row_mask & seat status ACTIVE/ALLIN) + TD target + forward + backward on the matrix cores -> gradient mean,
         clip_grad_norm_, AdamW, target sync every update_freq optimizer steps.  Returns the device tensor
         [rows trained on, MSE loss, gradient norm before clipping, 0] of this call (read it later, or never).
         Moments live in this path's own buffers (not in self.optimizer, which serves the torch train_step)."""
         states, next_states = self._rows(states), self._rows(next_states)
         n = states.shape[0]
-        t = self._native_state(n)
+        t = self._native_state()
 
         def u8(x):
             if x is None:

@@ -83,9 +83,12 @@ def test_hip_act_matches_oracle_and_leaves_other_seats_alone(g, eps):
     got = actions.cpu().numpy()
     assert (got[~sel] == -5).all() and sel.sum() > 400
     full = q.q_values(states).cpu().numpy()
-    np.testing.assert_array_equal(qrows.cpu().numpy()[sel], full[sel])           # same rows through the compacted tiles
+    mine = qrows.cpu().numpy()
+    # the masked kernel splits the k range of layers 3 and 4 over wavefronts: same values up to summation order
+    np.testing.assert_allclose(mine[sel], full[sel], rtol=0, atol=Q_TOL)
+    assert (mine[~sel] == 0).all()
     want = np.full(n, -5, dtype=np.int64)
-    orc.qnet_act(full, seat.cpu().numpy(), 3, eps, 4242, 77, 10_000_000_000, want)
+    orc.qnet_act(mine, seat.cpu().numpy(), 3, eps, 4242, 77, 10_000_000_000, want)    # actions follow the kernel's own Q rows
     np.testing.assert_array_equal(got, want)
     if eps == 1.0:
         counts = np.bincount(got[sel], minlength=13)
@@ -109,17 +112,31 @@ def test_get_actions_and_build_actions_fused_path(g):
     dev = torch.device(DEV)
     names = ["tight_aggressive", "heuristic_hands", "loose_passive", "random", "small_ball"]
     agents, types = load_gpu_agents(dev, 5, names, 100, 13)
-    agents.insert(0, q)
-    types.insert(0, PokerAgentType.QLEARNING)
+    agents.insert(3, q)                       # seat 3 opens the betting after a first reset (button 0, blinds 1 and 2)
+    types.insert(3, PokerAgentType.QLEARNING)
     env = PokerGPU(device=dev, agents=agents, n_players=6, max_players=10, n_games=4096, seed=1)
     state, info = env.reset(options={"active_players": 6})
     actions = torch.full((4096,), -9, dtype=torch.long, device=dev)
     build_actions(state, actions, info["seat_idx"], agents, types, dev)
     a = actions.cpu().numpy()
     assert ((a >= 0) & (a < 13)).all()
-    mine = info["seat_idx"].cpu().numpy() == 0
+    mine = info["seat_idx"].cpu().numpy() == 3
+    assert mine.all()
+    for _ in range(12):                       # play on until the tables wait on different seats, the learner's among them
+        state, _, _, _, info = env.step(actions)
+        actions.fill_(-9)
+        build_actions(state, actions, info["seat_idx"], agents, types, dev)
+        mine = info["seat_idx"].cpu().numpy() == 3
+        if 0 < mine.sum() < 4096:
+            break
+    a = actions.cpu().numpy()
+    assert ((a >= 0) & (a < 13)).all()
+    assert 0 < mine.sum() < 4096
     qv = q.q_values(state).cpu().numpy()
-    np.testing.assert_array_equal(a[mine], qv.argmax(axis=1)[mine])
+    top2 = np.sort(qv, axis=1)[:, -2:]
+    clear = mine & ((top2[:, 1] - top2[:, 0]) > 4 * Q_TOL)
+    assert clear.sum() > 0.5 * mine.sum() > 0
+    np.testing.assert_array_equal(a[clear], qv.argmax(axis=1)[clear])
 
 
 def test_train_step_masked_equals_filtered_train_step(g):
@@ -242,7 +259,7 @@ def test_native_gradient_matches_oracle_and_torch_autograd(g):
     n = 3000
     b = _batch(n, 42)
     dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
-    t = q._native_state(n)
+    t = q._native_state()
     t.lr, t.weight_decay = 0.0, 0.0                      # keep the parameters: only the gradient path is looked at
     p0 = _flat(q.network)
     from pulselib_amd import _native
