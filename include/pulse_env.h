@@ -233,35 +233,43 @@ int pulse_qnet_forward(const PulseQNet* net, const float* states, int64_t row_st
  * r with seat_idx[r] == q_seat (seat_idx NULL: every row) actions[r] = uniform{0..n_actions-1} with probability
  * epsilon, else the first argmax of the Q row; other rows are left untouched.  Draws are words x (explore) and y
  * (action) of Philox4x32-10(seed, table_id0 + r, step), the stream pulse_poker_policy uses for scripted seats.
- * q_out NULL or fp32[n_rows, n_actions] (selected rows written). */
+ * q_out NULL or fp32[n_rows, n_actions] (selected rows written).  row_mask_out (NULL or device uint8[n_rows], needs
+ * seat_idx): row_mask_out[r] = (seat_idx[r] == q_seat) && !terminated[r] (terminated NULL = none) for EVERY row --
+ * the trainer's `q_mask & ~terminated` (scripts/Poker/trainGPU.py:85), the row_mask of pulse_qnet_train_step. */
 int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows,
                    const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
-                   uint64_t table_id0, int64_t* actions, float* q_out, void* stream);
+                   uint64_t table_id0, int64_t* actions, float* q_out, const uint8_t* terminated,
+                   uint8_t* row_mask_out, void* stream);
 
-/* PokerQNetwork.train_step (Player.py:255-294) as two launches: row filter + TD target + forward (train mode) +
- * backward on the matrix cores, then gradient mean / clip_grad_norm_ / AdamW / target sync.  The network and its target each live in
- * ONE flat fp32 buffer of pulse_qnet_param_count() floats laid out w1,b1,w2,b2,w3,b3,w4,b4,w5,b5 (torch layouts);
- * `net` / `target` hold the ten views.  grad, exp_avg, exp_avg_sq: flat buffers of the same length, zero before the
- * first call (the call leaves grad zeroed again).  step: device int64 optimizer step count (bias correction, target
- * sync every update_freq steps).  stats: device fp32[2] scratch, zero before the first call.  report: device
- * fp32[4] out: [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping.
+/* PokerQNetwork.train_step (Player.py:255-294) as three launches: (1) row filter + TD target + forward (train mode)
+ * + backward on the matrix cores, gradient sums kept in registers and stored once per workgroup; (2) reduction of the
+ * workgroups' slices; (3) gradient mean / clip_grad_norm_ / AdamW / target sync, elementwise.
+ * The network and its target each live in ONE flat fp32 buffer of pulse_qnet_param_count() floats laid out
+ * w1,b1,w2,b2,w3,b3,w4,b4,w5,b5 (torch layouts); `net` / `target` hold the ten views.  grad, exp_avg, exp_avg_sq: flat
+ * buffers of the same length (moments zero before the first call).  partials: device fp32[max_blocks * (n_params + 4)]
+ * scratch (max_blocks = number of persistent workgroups, 256 = one per CU).  step: device int64 optimizer step count
+ * (bias correction, target sync every update_freq steps).  stats: device fp32[4] scratch.  report: device fp32[4] out:
+ * [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping.
  * Row filter: row_mask[r] != 0 (NULL: all) and states[r][12] in {0, 2} (:261); if no row passes, nothing changes (:262).
+ * Trainer bookkeeping folded in (both optional, scripts/Poker/trainGPU.py:86,96): terminated (device uint8[n_rows],
+ * NULL = skip) gets terminated[r] |= dones[r]; reward_sum (device double, NULL = skip) += sum of rewards over the
+ * row_mask rows (before the status filter).
  * Dropout(.1) after the 2nd and 3rd GELU draws 16-bit uniforms from Philox4x32-10(seed ^ 0xD50F0D50F0, table_id0 + r,
- * 32 * step_counter + unit / 8); dropout_p = 0 disables it.  fp32 atomics: gradient sums are order-dependent at
- * rounding level. */
+ * 32 * step_counter + unit / 8); dropout_p = 0 disables it.  Sums over rows run in workgroup order: deterministic for
+ * a given n_rows and max_blocks. */
 typedef struct PulseQNetTrain {
     PulseQNet net, target;
     float *params, *target_params, *grad, *exp_avg, *exp_avg_sq;
     int64_t* step;
-    float *stats, *report;
+    float *stats, *report, *partials;
     float lr, weight_decay, beta1, beta2, eps, max_grad_norm, gamma, dropout_p;
-    int32_t update_freq, reserved0;
+    int32_t update_freq, max_blocks;
 } PulseQNetTrain;
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions);
 int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter,
-                          uint64_t table_id0, void* stream);
+                          uint64_t table_id0, uint8_t* terminated, double* reward_sum, void* stream);
 
 /* ---- Particle2D (environments/Particle2D/Particle2D.py:22-30) ---------------------------------- */
 int pulse_particle2d_step(float* state, const float* action, int32_t* steps, float* obs_out, float* rewards,

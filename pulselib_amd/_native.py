@@ -59,9 +59,9 @@ class QNet(C.Structure):
 
 class QNetTrain(C.Structure):
     _fields_ = [("net", QNet), ("target", QNet)] + [(n, C.c_void_p) for n in (
-        "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report")] + [(n, C.c_float) for n in (
+        "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report", "partials")] + [(n, C.c_float) for n in (
             "lr", "weight_decay", "beta1", "beta2", "eps", "max_grad_norm", "gamma", "dropout_p")] + [
-        ("update_freq", C.c_int32), ("reserved0", C.c_int32)]
+        ("update_freq", C.c_int32), ("max_blocks", C.c_int32)]
 
 
 class QTable(C.Structure):
@@ -100,9 +100,9 @@ SYMBOLS = {
     "pulse_qtable_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, C.c_double, C.c_double, _P]),
     "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
     "pulse_qnet_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
-    "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P]),
+    "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P, _P, _P]),
     "pulse_qnet_param_count": (C.c_int, [_I32, _I32]),
-    "pulse_qnet_train_step": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I32, _U64, _U64, _U64, _P]),
+    "pulse_qnet_train_step": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I32, _U64, _U64, _U64, _P, _P, _P]),
 }
 
 

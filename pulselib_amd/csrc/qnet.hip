@@ -28,6 +28,19 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// In-kernel timeline of the training kernel (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so,
+// tools/qnet_stamp_timeline.py): lane 0 of wavefront 0 stores the clock at phase boundaries of its first tile.
+#ifndef PULSE_STAMPS
+#define PULSE_STAMPS 0
+#endif
+#if PULSE_STAMPS
+__device__ unsigned long long* g_qstamp_buf = nullptr;
+#define QSTAMP(i) do { if (threadIdx.x == 0 && g_qstamp_buf) { __builtin_amdgcn_sched_barrier(0); \
+    g_qstamp_buf[(size_t)blockIdx.x * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define QSTAMP(i) do { } while (0)
+#endif
+
 struct U4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset) {
     uint32_t c0 = (uint32_t)offset, c1 = (uint32_t)(offset >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
@@ -97,6 +110,7 @@ struct QNetArgs {
     float epsilon; uint64_t seed, step, table_id0;
     int64_t* actions;                                // nullptr: no action selection (plain forward)
     float* q_out;                                    // nullptr or fp32[n_rows, n_actions]
+    const uint8_t* terminated; uint8_t* row_mask_out; // masked form only: row_mask_out[r] = selected && !terminated[r]
 };
 
 // The network in eval mode on up to 32 rows: lane (c, h) carries the row at `xr` (`live` false = padding column,
@@ -224,9 +238,20 @@ struct CoopLds {                 // offsets in floats into the dynamic LDS block
 constexpr size_t kActLdsBytes = (size_t)CoopLds::EndEval * sizeof(float);
 constexpr size_t kTrainLdsBytes = (size_t)CoopLds::EndTrain * sizeof(float);
 
-__device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+// GELU and its derivative for the cooperative kernels, sharing one exponential: with e = exp(-x^2 / 2),
+//   erf(|x| / sqrt 2) = 1 - (a1 t + ... + a5 t^5) e,  t = 1 / (1 + p |x| / sqrt 2)      (Abramowitz-Stegun 7.1.26,
+// |error| <= 1.5e-7, the size of an fp32 rounding of the result), and the density in gelu' is e / sqrt(2 pi).  Branch-free
+// and ~20 instructions for the pair; the library erff (three data-dependent branches, all taken in a wavefront
+// of mixed arguments) was 60 % of the training kernel.  Differences to torch's erff-based GELU stay at 1e-7 |x|.
+__device__ __forceinline__ void gelu_pair(float x, float& y, float& dy) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = 1.0f - poly * e;
+    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    y = x * cdf;
+    dy = cdf + x * 0.39894228040143267794f * e;
 }
 
 // store an accumulator tile as [unit0 + row-of-tile][column]
@@ -251,25 +276,34 @@ __device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t gi
     return bits;
 }
 
-// acc[out, row] = sum over k in [k0, k1) of W[out_row][k] * S[k][row]; k0, k1 multiples of 8.  VEC: W rows are
+// acc[out, row] = sum over the NK8 steps of 8 k from k0 (k < k1) of W[out_row][k] * S[k][row].  All the weight loads
+// of the call are issued before the first MFMA (the loop is otherwise one L2 round trip per four MFMAs).  VEC: W rows are
 // 16-byte aligned and K % 8 == 0 (a float4 feeds four MFMAs); else scalar loads guarded by k < K.
-template <bool VEC>
+template <bool VEC, int NK8>
 __device__ __forceinline__ f32x16 dense_lds(const float* __restrict__ w, int K, int out_row, int c, int h, const float* __restrict__ S,
                                             int k0, int k1) {
-    f32x16 acc = zero16();
     const float* wr = w + (size_t)out_row * K;
-    for (int k8 = k0; k8 < k1; k8 += 8) {
-        const int k = k8 + 4 * h;
-        float wa[4];
+    float wa[NK8][4];
+#pragma unroll
+    for (int i = 0; i < NK8; ++i) {
+        const int k = k0 + 8 * i + 4 * h;
         if (VEC) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
-            wa[0] = w4.x; wa[1] = w4.y; wa[2] = w4.z; wa[3] = w4.w;
+            float4 w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k0 + 8 * i < k1) w4 = *reinterpret_cast<const float4*>(wr + k);
+            wa[i][0] = w4.x; wa[i][1] = w4.y; wa[i][2] = w4.z; wa[i][3] = w4.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = k + j < K ? wr[k + j] : 0.0f;
+            for (int j = 0; j < 4; ++j) wa[i][j] = (k0 + 8 * i < k1 && k + j < K) ? wr[k + j] : 0.0f;
         }
+    }
+    f32x16 acc = zero16();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], S[(k + j) * kLd + c], acc, 0, 0, 0);
+    for (int i = 0; i < NK8; ++i) {
+        const int k = k0 + 8 * i + 4 * h;
+        if (k0 + 8 * i < k1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][j], S[(k + j) * kLd + c], acc, 0, 0, 0);
+        }
     }
     return acc;
 }
@@ -283,8 +317,10 @@ __device__ __forceinline__ void coop_epilogue(const f32x16& acc, const float* __
         const int u = unit0 + rho(r) + 4 * h;
         const float z = acc[r] + bias[u];
         const float m = ((keep >> r) & 1u) ? scale : 0.0f;
-        As[u * kLd + c] = gelu(z) * m;
-        if (TRAIN) Gs[u * kLd + c] = gelu_grad(z) * m;
+        float y, dy;
+        gelu_pair(z, y, dy);
+        As[u * kLd + c] = y * m;
+        if (TRAIN) Gs[u * kLd + c] = dy * m;
     }
 }
 
@@ -310,19 +346,19 @@ __device__ __forceinline__ f32x16 coop_forward(const PulseQNet& n, float* __rest
     const int lane = c + 32 * h, K1 = n.state_dim, K1r = (K1 + 7) & ~7;
     __syncthreads();                                                          // Xs complete
     {   // layer 1: wavefront wv -> units [32wv, +32)
-        const f32x16 acc = dense_lds<VEC>(n.w1, K1, 32 * wv + c, c, h, Xs, 0, K1r);
+        const f32x16 acc = dense_lds<VEC, 8>(n.w1, K1, 32 * wv + c, c, h, Xs, 0, K1r);
         coop_epilogue<TRAIN>(acc, n.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, G1);
     }
     __syncthreads();
     {   // layer 2 (+ Dropout, Player.py:194)
-        const f32x16 acc = dense_lds<true>(n.w2, 128, 32 * wv + c, c, h, A1, 0, 128);
+        const f32x16 acc = dense_lds<true, 16>(n.w2, 128, 32 * wv + c, c, h, A1, 0, 128);
         const uint32_t keep = TRAIN ? dropout_keep_bits(seed, gid, step, wv, h, thr) : 0xFFFFu;
         coop_epilogue<TRAIN>(acc, n.b2, 32 * wv, c, h, keep, TRAIN ? scale : 1.0f, A2, G2);
     }
     __syncthreads();
     {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197)
         const int ot = wv & 1, half = wv >> 1;
-        f32x16 acc = dense_lds<true>(n.w3, 128, 32 * ot + c, c, h, A2, 64 * half, 64 * half + 64);
+        f32x16 acc = dense_lds<true, 8>(n.w3, 128, 32 * ot + c, c, h, A2, 64 * half, 64 * half + 64);
         if (half == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[(ot * 16 + r) * 64 + lane] = acc[r];
@@ -337,7 +373,7 @@ __device__ __forceinline__ f32x16 coop_forward(const PulseQNet& n, float* __rest
     }
     __syncthreads();
     {   // layer 4: one output tile, k in quarters
-        f32x16 acc = dense_lds<true>(n.w4, 64, c, c, h, A3, 16 * wv, 16 * wv + 16);
+        f32x16 acc = dense_lds<true, 2>(n.w4, 64, c, c, h, A3, 16 * wv, 16 * wv + 16);
         if (wv > 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[((wv - 1) * 16 + r) * 64 + lane] = acc[r];
@@ -352,7 +388,7 @@ __device__ __forceinline__ f32x16 coop_forward(const PulseQNet& n, float* __rest
     __syncthreads();
     f32x16 qv = zero16();
     if (wv == 0) {
-        qv = dense_lds<true>(n.w5, 32, min(c, n.n_actions - 1), c, h, A4, 0, 32);
+        qv = dense_lds<true, 4>(n.w5, 32, min(c, n.n_actions - 1), c, h, A4, 0, 32);
         bias_act<false>(qv, n.b5, 0, n.n_actions, h);
     }
     return qv;
@@ -381,6 +417,8 @@ __global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * 256 + threadIdx.x;
     const bool sel = row < a.n_rows && a.seat_idx[row] == a.q_seat;
+    if (a.row_mask_out && row < a.n_rows)            // the trainer's `q_mask & ~terminated` (trainGPU.py:85) rides along
+        a.row_mask_out[row] = (sel && !(a.terminated && a.terminated[row])) ? 1 : 0;
     const int count = coop_compact(lds, sel, row);
     const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
     const int A = a.net.n_actions;
@@ -413,41 +451,47 @@ __global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
 }
 
 // ================================================================ training step (Player.py:255-294)
-// One launch does, for the rows that pass the reference's filters, what train_step does between its masks and
-// `loss.backward()`: TD target from the target network, forward in train mode (dropout after the 2nd and 3rd GELU),
-// d(loss)/d(parameters) -- accumulated UNNORMALISED (the 1 / #valid-rows of MSELoss, the norm clipping and AdamW
-// follow in qnet_adamw_kernel, which knows the global row count).  Per tile of 32 rows, on one CU:
+// Launch 1 (qnet_train_kernel) does, for the rows that pass the reference's filters, what train_step does between
+// its masks and `loss.backward()`: TD target from the target network, forward in train mode (dropout after the 2nd
+// and 3rd GELU), d(loss)/d(parameters) -- UNNORMALISED sums (the 1 / #valid-rows of MSELoss, the norm clipping and
+// AdamW follow in launches 2 and 3, which know the global row count).  Per tile of 32 rows, on one CU:
 //   target    cooperative forward of the target network on s', max over actions -> Tgt[row];
 //   forward   cooperative forward of the network on s; every hidden layer leaves a_l and g_l = gelu'(z_l) * dropout
 //             scale in LDS;  delta_5 = 2 (q[action] - target) on the action's row of the output tile;
 //   backward  per layer, dealt to the 4 wavefronts: the 32x32 blocks of dW_l = delta_l . a_{l-1}^T (both operands read
-//             out of LDS with the row index as the MFMA k: 16 MFMAs per block, then one f32 atomic per element into the
-//             flat gradient; db_l falls out of the same reads) and the tiles of
-//             delta_{l-1} = (W_l^T . delta_l) * g_{l-1} (A operand = W_l read down its columns, coalesced).
-// fp32 atomics make the summation order of the gradient vary from run to run (rounding-level differences).
+//             out of LDS with the row index as the MFMA k, 16 MFMAs per block per tile; db_l falls out of the same
+//             reads) and the tiles of delta_{l-1} = (W_l^T . delta_l) * g_{l-1} (A operand = W_l read down its
+//             columns, coalesced).
+// Every wavefront owns the same 8-10 blocks of dW for the whole launch and accumulates them, tile after tile, in its
+// workgroup's private slice of `partials` (plain read-modify-write, L2-resident; the workgroups are persistent: at
+// most `max_blocks` of them stride over the 256-row windows) -- no atomics: float atomics from 8 XCDs onto 32 K
+// shared addresses were 80 % of this kernel's time in the first version.
+// Launch 2 (qnet_grad_reduce_kernel) sums the slices into the flat gradient and its squared norm; launch 3
+// (qnet_adamw_kernel) is mean / clip_grad_norm_ / AdamW / target sync, elementwise over the parameters.
 struct TrainArgs {
     PulseQNet net, tgt;
-    float* grad; float* stats;                // flat gradient (layout: w1,b1,...,w5,b5), stats[0]=#valid rows, [1]=sum td^2
+    float* partials;                          // [gridDim.x][n_params + 4]: gradient sums, then {rows, sum td^2, sum reward, -}
+    float* scal;                              // scal[0] = squared gradient norm of the reduce launch: cleared here for it
+    int n_params;
     const float* states; long long stride;
     const int64_t* actions; const float* rewards;
     const float* next_states; long long next_stride;
     const uint8_t* dones; const uint8_t* row_mask;
+    uint8_t* terminated;                      // nullptr or in/out: terminated[r] |= dones[r] for every row (trainGPU.py:86)
     int n_rows;
     uint64_t seed, step, table_id0;
     float gamma, drop_p;
 };
 
-// block (ot, it) of dW for a layer with n_out x n_in weights: delta in D, a_{l-1} in Ap; BIAS: also db rows of tile ot
-template <bool BIAS>
-__device__ __forceinline__ void dw_block(const float* __restrict__ D, const float* __restrict__ Ap, float* __restrict__ gw,
-                                         float* __restrict__ gb, int n_out, int n_in, int ot, int it, int c, int h) {
-    float ad[16]; float bsum = 0.0f;
+// block (ot, it) of dW += delta . a^T for this tile, into the workgroup's own slice (plain read-modify-write: a block
+// of a slice belongs to one wavefront for the whole launch; `first` = nothing accumulated yet); delta in D, a_{l-1} in
+// Ap; bsum: this tile's db rows of tile ot
+__device__ __forceinline__ void dw_accum(const float* __restrict__ D, const float* __restrict__ Ap, float* __restrict__ gw, int n_out, int n_in,
+                                         int ot, int it, int c, int h, bool first, float* bsum) {
+    float ad[16]; float bs = 0.0f;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) { ad[s2] = D[(32 * ot + c) * kLd + 2 * s2 + h]; bsum += ad[s2]; }
-    if (BIAS) {
-        bsum += __shfl_xor(bsum, 32);
-        if (h == 0 && 32 * ot + c < n_out) unsafeAtomicAdd(gb + 32 * ot + c, bsum);
-    }
+    for (int s2 = 0; s2 < 16; ++s2) { ad[s2] = D[(32 * ot + c) * kLd + 2 * s2 + h]; bs += ad[s2]; }
+    if (bsum) *bsum += bs + __shfl_xor(bs, 32);
     f32x16 acc = zero16();
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s2], Ap[(32 * it + c) * kLd + 2 * s2 + h], acc, 0, 0, 0);
@@ -455,19 +499,27 @@ __device__ __forceinline__ void dw_block(const float* __restrict__ D, const floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = 32 * ot + rho(r) + 4 * h;
-        if (o < n_out && in < n_in) unsafeAtomicAdd(gw + (size_t)o * n_in + in, acc[r]);
+        if (o < n_out && in < n_in) {
+            float* p = gw + (size_t)o * n_in + in;
+            *p = first ? acc[r] : *p + acc[r];
+        }
     }
 }
 
-// tile `it` of delta_{l-1} = (W^T . delta_l) * g_{l-1} -> Dn[32 it ..]; W is n_out x n_in, delta_l = units [0, ku) of D
-__device__ __forceinline__ void back_block(const float* __restrict__ w, int n_out, int n_in, int it, const float* __restrict__ D, int ku,
+// tile `it` of delta_{l-1} = (W^T . delta_l) * g_{l-1} -> Dn[32 it ..]; W is n_out x n_in, delta_l = units [0, KU) of D.
+// The KU / 2 weight loads (one per MFMA, down a column of W) are issued before the first MFMA.
+template <int KU>
+__device__ __forceinline__ void back_block(const float* __restrict__ w, int n_out, int n_in, int it, const float* __restrict__ D,
                                            const float* __restrict__ G, float* __restrict__ Dn, int c, int h) {
-    f32x16 acc = zero16();
-    for (int k2 = 0; k2 < ku; k2 += 2) {
-        const int k = k2 + h;
-        const float wa = k < n_out ? w[(size_t)k * n_in + 32 * it + c] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, D[k * kLd + c], acc, 0, 0, 0);
+    float wa[KU / 2];
+#pragma unroll
+    for (int i = 0; i < KU / 2; ++i) {
+        const int k = 2 * i + h;
+        wa[i] = k < n_out ? w[(size_t)k * n_in + 32 * it + c] : 0.0f;
     }
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int i = 0; i < KU / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], D[(2 * i + h) * kLd + c], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int u = 32 * it + rho(r) + 4 * h;
@@ -479,15 +531,8 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     extern __shared__ float lds[];
     const PulseQNet& n = a.net;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane & 31, h0 = lane >> 5;
     const int K1 = n.state_dim, A = n.n_actions;
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    bool sel = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
-    if (sel) {                                                   // seat status ACTIVE or ALLIN, Player.py:261
-        const float status = a.states[(size_t)row * a.stride + 12];
-        sel = status == 0.0f || status == 2.0f;
-    }
-    const int count = coop_compact(lds, sel, row);
     const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
     float* A4 = lds + CoopLds::A4; float* Tgt = lds + CoopLds::Tgt;
@@ -498,135 +543,212 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     const uint32_t thr = (uint32_t)(a.drop_p * 65536.0f);
     const float scale = 1.0f / (1.0f - a.drop_p);
 
-    for (int t0 = 0; t0 < count; t0 += 32) {
-        const int rowc = t0 + c < count ? list[t0 + c] : -1;
-        const bool live = rowc >= 0;
-        const int rw = max(rowc, 0);
-        const uint64_t gid = a.table_id0 + (uint64_t)rw;
-        // target: r + gamma * max_a' Q_target(s', a') * (1 - done)                                   (:275-277)
-        __syncthreads();
-        coop_load_rows(lds, a.next_states, a.next_stride, K1, rowc, wv, c, h);
-        {
-            const f32x16 qn = coop_forward<false, VEC>(a.tgt, lds, wv, c, h, 0, 0, 0, 0, 1.0f);
-            if (wv == 0) {
-                float best = -INFINITY;
+    // this wavefront's rows of db, live across every tile of the launch (its blocks of dW accumulate in the slice)
+    float b5 = 0.0f, b4 = 0.0f, b3 = 0.0f, b2 = 0.0f, b1 = 0.0f;
+    float rows_sum = 0.0f, sq_sum = 0.0f;                        // wavefront 0, lane-replicated after the reductions
+    float reward_sum = 0.0f;                                     // this wavefront's candidate rows
+    bool used = false;
+    float* part = a.partials + (size_t)blockIdx.x * (a.n_params + 4);
+
+    // scal[0] is read by every workgroup of the previous step's AdamW launch and accumulated by this step's reduce
+    // launch: this kernel sits between the two on the stream, so its first thread clears it
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[0] = 0.0f;
+    QSTAMP(0);
+    const int n_windows = (a.n_rows + 255) / 256;
+    for (int win = blockIdx.x; win < n_windows; win += gridDim.x) {
+        const int row = win * 256 + threadIdx.x;
+        bool sel = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
+        float rew = sel ? a.rewards[row] : 0.0f;                 // episode reward: rows of row_mask, before the status filter (trainGPU.py:96)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) if (rho(r) + 4 * h < A) best = fmaxf(best, qn[r]);
-                best = fmaxf(best, __shfl_xor(best, 32));
-                const float notdone = (live && a.dones[rw]) ? 0.0f : 1.0f;
-                if (h == 0) Tgt[c] = (live ? a.rewards[rw] : 0.0f) + a.gamma * best * notdone;
+        for (int off = 32; off >= 1; off >>= 1) rew += __shfl_xor(rew, off);
+        reward_sum += rew;
+        if (a.terminated && row < a.n_rows && a.dones[row]) a.terminated[row] = 1;
+        if (sel) {                                               // seat status ACTIVE or ALLIN, Player.py:261
+            const float status = a.states[(size_t)row * a.stride + 12];
+            sel = status == 0.0f || status == 2.0f;
+        }
+        __syncthreads();                                         // previous window's tiles are done with List
+        const int count = coop_compact(lds, sel, row);
+        for (int t0 = 0; t0 < count; t0 += 32) {
+            const bool first = !used;
+            used = true;
+            // the addresses below depend only on the wavefront and the lane: without this opaque zero the compiler
+            // hoists a few hundred of them out of the tile loop and spills them
+            int opaque = 0;
+            asm volatile("" : "+s"(opaque));
+            float* part_t = part + opaque;
+            int c = c0, h = h0;
+            asm volatile("" : "+v"(c), "+v"(h));
+            const int rowc = t0 + c < count ? list[t0 + c] : -1;
+            const bool live = rowc >= 0;
+            const int rw = max(rowc, 0);
+            const uint64_t gid = a.table_id0 + (uint64_t)rw;
+            // target: r + gamma * max_a' Q_target(s', a') * (1 - done)                               (:275-277)
+            __syncthreads();
+            QSTAMP(1);
+            coop_load_rows(lds, a.next_states, a.next_stride, K1, rowc, wv, c, h);
+            {
+                const f32x16 qn = coop_forward<false, VEC>(a.tgt, lds, wv, c, h, 0, 0, 0, 0, 1.0f);
+                if (wv == 0) {
+                    float best = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (rho(r) + 4 * h < A) best = fmaxf(best, qn[r]);
+                    best = fmaxf(best, __shfl_xor(best, 32));
+                    const float notdone = (live && a.dones[rw]) ? 0.0f : 1.0f;
+                    if (h == 0) Tgt[c] = (live ? a.rewards[rw] : 0.0f) + a.gamma * best * notdone;
+                }
             }
-        }
-        __syncthreads();
-        // forward, train mode
-        coop_load_rows(lds, a.states, a.stride, K1, rowc, wv, c, h);
-        {
-            const f32x16 qv = coop_forward<true, VEC>(n, lds, wv, c, h, a.seed, gid, a.step, thr, scale);
-            if (wv == 0) {                                                    // delta_5 and the loss terms (:270-279)
-                const int act = live ? (int)a.actions[rw] : -1;
-                float qa = 0.0f;
+            __syncthreads();
+            QSTAMP(2);
+            // forward, train mode
+            coop_load_rows(lds, a.states, a.stride, K1, rowc, wv, c, h);
+            {
+                const f32x16 qv = coop_forward<true, VEC>(n, lds, wv, c, h, a.seed, gid, a.step, thr, scale);
+                if (wv == 0) {                                                // delta_5 and the loss terms (:270-279)
+                    const int act = live ? (int)a.actions[rw] : -1;
+                    float qa = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) qa += (rho(r) + 4 * h == act) ? qv[r] : 0.0f;
-                qa += __shfl_xor(qa, 32);
-                const float td = live ? qa - Tgt[c] : 0.0f;
+                    for (int r = 0; r < 16; ++r) qa += (rho(r) + 4 * h == act) ? qv[r] : 0.0f;
+                    qa += __shfl_xor(qa, 32);
+                    const float td = live ? qa - Tgt[c] : 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Da[(rho(r) + 4 * h) * kLd + c] = (rho(r) + 4 * h == act) ? 2.0f * td : 0.0f;
-                float sq = (h == 0) ? td * td : 0.0f, cnt = (h == 0 && live) ? 1.0f : 0.0f;
+                    for (int r = 0; r < 16; ++r) Da[(rho(r) + 4 * h) * kLd + c] = (rho(r) + 4 * h == act) ? 2.0f * td : 0.0f;
+                    float sq = (h == 0) ? td * td : 0.0f, cnt = (h == 0 && live) ? 1.0f : 0.0f;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { sq += __shfl_xor(sq, off); cnt += __shfl_xor(cnt, off); }
-                if (lane == 0) { unsafeAtomicAdd(a.stats + 0, cnt); unsafeAtomicAdd(a.stats + 1, sq); }
+                    for (int off = 32; off >= 1; off >>= 1) { sq += __shfl_xor(sq, off); cnt += __shfl_xor(cnt, off); }
+                    rows_sum += cnt; sq_sum += sq;
+                }
             }
-        }
-        __syncthreads();
-        // layer 5 (delta_5 in Da): dW5 | delta_4 -> Db
-        if (wv == 0) dw_block<true>(Da, A4, a.grad + o_w5, a.grad + o_b5, A, 32, 0, 0, c, h);
-        if (wv == 1) back_block(n.w5, A, 32, 0, Da, 32, G4, Db, c, h);
-        __syncthreads();
-        // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
-        if (wv == 0) dw_block<true>(Db, A3, a.grad + o_w4, a.grad + o_b4, 32, 64, 0, 0, c, h);
-        if (wv == 1) dw_block<false>(Db, A3, a.grad + o_w4, a.grad + o_b4, 32, 64, 0, 1, c, h);
-        if (wv >= 2) back_block(n.w4, 32, 64, wv - 2, Db, 32, G3, Da, c, h);
-        __syncthreads();
-        // layer 3 (delta_3 in Da): 8 dW blocks, 2 per wavefront | delta_2 tile wv -> Db
-        dw_block<false>(Da, A2, a.grad + o_w3, a.grad + o_b3, 64, 128, 0, wv, c, h);
-        dw_block<false>(Da, A2, a.grad + o_w3, a.grad + o_b3, 64, 128, 1, wv, c, h);
-        if (wv < 2) {                                                         // db3 rows of tile wv
-            float bsum = 0.0f;
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) bsum += Da[(32 * wv + c) * kLd + 2 * s2 + h];
-            bsum += __shfl_xor(bsum, 32);
-            if (h == 0) unsafeAtomicAdd(a.grad + o_b3 + 32 * wv + c, bsum);
-        }
-        back_block(n.w3, 64, 128, wv, Da, 64, G2, Db, c, h);
-        __syncthreads();
-        // layer 2 (delta_2 in Db): 16 dW blocks, column tile wv of each row tile | delta_1 tile wv -> Da
+            __syncthreads();
+            QSTAMP(3);
+            // layer 5 (delta_5 in Da): dW5 | delta_4 -> Db
+            if (wv == 0) dw_accum(Da, A4, part_t + o_w5, A, 32, 0, 0, c, h, first, &b5);
+            if (wv == 1) back_block<32>(n.w5, A, 32, 0, Da, G4, Db, c, h);
+            __syncthreads();
+            QSTAMP(4);
+            // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
+            if (wv == 0) dw_accum(Db, A3, part_t + o_w4, 32, 64, 0, 0, c, h, first, &b4);
+            if (wv == 1) dw_accum(Db, A3, part_t + o_w4, 32, 64, 0, 1, c, h, first, nullptr);
+            if (wv >= 2) back_block<32>(n.w4, 32, 64, wv - 2, Db, G3, Da, c, h);
+            __syncthreads();
+            QSTAMP(5);
+            // layer 3 (delta_3 in Da): 8 dW blocks, column tile wv of both row tiles | delta_2 tile wv -> Db
+            dw_accum(Da, A2, part_t + o_w3, 64, 128, 0, wv, c, h, first, wv == 0 ? &b3 : nullptr);
+            dw_accum(Da, A2, part_t + o_w3, 64, 128, 1, wv, c, h, first, wv == 1 ? &b3 : nullptr);
+            back_block<64>(n.w3, 64, 128, wv, Da, G2, Db, c, h);
+            __syncthreads();
+            QSTAMP(6);
+            // layer 2 (delta_2 in Db): 16 dW blocks, column tile wv of each row tile | delta_1 tile wv -> Da
 #pragma unroll 1
-        for (int ot = 0; ot < 4; ++ot) dw_block<false>(Db, A1, a.grad + o_w2, a.grad + o_b2, 128, 128, ot, wv, c, h);
-        {
-            float bsum = 0.0f;                                                // db2 rows of tile wv
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) bsum += Db[(32 * wv + c) * kLd + 2 * s2 + h];
-            bsum += __shfl_xor(bsum, 32);
-            if (h == 0) unsafeAtomicAdd(a.grad + o_b2 + 32 * wv + c, bsum);
+            for (int ot = 0; ot < 4; ++ot) dw_accum(Db, A1, part_t + o_w2, 128, 128, ot, wv, c, h, first, ot == wv ? &b2 : nullptr);
+            back_block<128>(n.w2, 128, 128, wv, Db, G1, Da, c, h);
+            __syncthreads();
+            QSTAMP(7);
+            // layer 1 (delta_1 in Da): row tile wv x the two column tiles of the input
+            dw_accum(Da, Xs, part_t + 0, 128, K1, wv, 0, c, h, first, &b1);
+            if (K1 > 32) dw_accum(Da, Xs, part_t + 0, 128, K1, wv, 1, c, h, first, nullptr);
         }
-        back_block(n.w2, 128, 128, wv, Db, 128, G1, Da, c, h);
-        __syncthreads();
-        // layer 1 (delta_1 in Da): row tile wv x the two column tiles of the input
-        dw_block<true>(Da, Xs, a.grad + 0, a.grad + o_b1, 128, K1, wv, 0, c, h);
-        if (K1 > 32) dw_block<false>(Da, Xs, a.grad + 0, a.grad + o_b1, 128, K1, wv, 1, c, h);
+    }
+
+    QSTAMP(8);
+    if (!used) {                                                  // no valid row in any of this workgroup's windows: a zero slice
+        for (int i = threadIdx.x; i < a.n_params; i += 256) part[i] = 0.0f;
+    }
+    // db rows: every bias is written by exactly one wavefront
+    if (used && h0 == 0) {
+        if (wv == 0) { if (c0 < A) part[o_b5 + c0] = b5; part[o_b4 + c0] = b4; }
+        if (wv < 2) part[o_b3 + 32 * wv + c0] = b3;
+        part[o_b2 + 32 * wv + c0] = b2;
+        part[o_b1 + 32 * wv + c0] = b1;
+    }
+    float* wave_reward = lds + CoopLds::List + 260;               // 4 spare words behind the compaction counters
+    __syncthreads();
+    if (lane == 0) wave_reward[wv] = reward_sum;
+    __syncthreads();
+    if (wv == 0 && lane == 0) {
+        float* ps = part + a.n_params;
+        ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = (wave_reward[0] + wave_reward[1]) + (wave_reward[2] + wave_reward[3]);
+        ps[3] = used ? 1.0f : 0.0f;
+    }
+    QSTAMP(9);
+}
+
+// Launch 2: flat gradient = sum of the used slices; scal[0] += its squared norm (one atomic per workgroup); workgroup 0
+// also totals the row count / squared TD error / reward and advances the optimizer step when there is something to learn.
+struct ReduceArgs {
+    const float* partials; int n_blocks, n_params;
+    float* grad; float* scal;                 // scal: [0] sum g^2 (zeroed here by the previous step's AdamW), [1] rows, [2] sum td^2
+    long long* step; double* reward_sum;      // reward_sum: nullptr or += sum of rewards over row_mask rows
+};
+
+__global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t pitch = (size_t)a.n_params + 4;
+    float g = 0.0f;
+    if (i < a.n_params) {
+        const float* p = a.partials + i;
+        int b = 0;
+        for (; b + 8 <= a.n_blocks; b += 8) {                 // eight independent loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + u) * pitch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += v[u];
+        }
+        for (; b < a.n_blocks; ++b) g += p[(size_t)b * pitch];
+        a.grad[i] = g;
+    }
+    float ss = g * g;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(a.scal + 0, (red[0] + red[1]) + (red[2] + red[3]));
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float rows = 0.0f, sq = 0.0f; double rew = 0.0;
+        for (int b = threadIdx.x; b < a.n_blocks; b += 64) {
+            const float* ps = a.partials + b * pitch + a.n_params;
+            rows += ps[0]; sq += ps[1]; rew += (double)ps[2];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { rows += __shfl_xor(rows, off); sq += __shfl_xor(sq, off); rew += __shfl_xor(rew, off); }
+        if (threadIdx.x == 0) {
+            a.scal[1] = rows; a.scal[2] = sq;
+            if (rows > 0.0f) *a.step += 1;
+            if (a.reward_sum) *a.reward_sum += rew;
+        }
     }
 }
 
-// Everything between loss.backward() and the end of train_step (Player.py:281-292), one workgroup:
-// gradient /= #valid rows (MSELoss mean), clip_grad_norm_(max_norm) (:280), AdamW (torch semantics: decoupled decay,
-// bias-corrected moments), step += 1, target sync every update_freq steps (:289-290); clears the gradient and the
-// statistics for the next step.  No valid row: nothing moves (the reference returns before the optimizer, :262).
+// Launch 3, elementwise over the parameters: everything between loss.backward() and the end of train_step
+// (Player.py:280-292): gradient /= #valid rows (MSELoss mean), clip_grad_norm_(max_norm), AdamW (torch semantics:
+// decoupled decay, bias-corrected moments), target sync every update_freq optimizer steps (:289-290).  No valid row:
+// nothing moves (the reference returns before the optimizer, :262).
 struct AdamArgs {
-    float* params; float* target; float* grad; float* m; float* v; long long* step; float* stats; float* report;
+    float* params; float* target; const float* grad; float* m; float* v; const long long* step; float* scal; float* report;
     int n_params; float lr, wd, beta1, beta2, eps, max_norm; int update_freq;
 };
 
-__global__ __launch_bounds__(1024) void qnet_adamw_kernel(const AdamArgs a) {
-    __shared__ float red[16];
-    __shared__ float s_coef;
-    const int tid = threadIdx.x;
-    const float count = a.stats[0], sq = a.stats[1];
+__global__ __launch_bounds__(256) void qnet_adamw_kernel(const AdamArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float count = a.scal[1], sq = a.scal[2], ss = a.scal[0];
     const float inv = count > 0.0f ? 1.0f / count : 0.0f;
-    float ss = 0.0f;
-    for (int i = tid; i < a.n_params; i += 1024) { const float g = a.grad[i] * inv; ss += g * g; }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.0f;
-        for (int i = 0; i < 16; ++i) t += red[i];
-        const float norm = sqrtf(t);
-        s_coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);                       // torch.nn.utils.clip_grad_norm_
-        a.report[0] = count; a.report[1] = count > 0.0f ? sq * inv : 0.0f; a.report[2] = norm;
-    }
-    __syncthreads();
-    const long long t_new = *a.step + 1;
-    __syncthreads();
-    if (count > 0.0f) {
-        const float coef = s_coef * inv;
-        const float bc1 = 1.0f - powf(a.beta1, (float)t_new), bc2 = 1.0f - powf(a.beta2, (float)t_new);
+    const float norm = sqrtf(ss) * inv;                                           // norm of the mean gradient
+    if (count > 0.0f && i < a.n_params) {
+        const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f) * inv;        // torch.nn.utils.clip_grad_norm_
+        const long long t = *a.step;                                              // already advanced by the reduce launch
+        const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
         const float step_size = a.lr / bc1, bc2_sqrt = sqrtf(bc2);
-        const bool sync = a.update_freq > 0 && (t_new % a.update_freq) == 0;
-        for (int i = tid; i < a.n_params; i += 1024) {
-            const float g = a.grad[i] * coef;
-            float p = a.params[i] * (1.0f - a.lr * a.wd);
-            const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
-            const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
-            const float denom = sqrtf(v) / bc2_sqrt + a.eps;
-            p -= step_size * (m / denom);
-            a.m[i] = m; a.v[i] = v; a.params[i] = p;
-            if (sync) a.target[i] = p;
-        }
-        if (tid == 0) *a.step = t_new;
+        const float g = a.grad[i] * coef;
+        float p = a.params[i] * (1.0f - a.lr * a.wd);
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        p -= step_size * (m / (sqrtf(v) / bc2_sqrt + a.eps));
+        a.m[i] = m; a.v[i] = v; a.params[i] = p;
+        if (a.update_freq > 0 && (t % a.update_freq) == 0) a.target[i] = p;
     }
-    for (int i = tid; i < a.n_params; i += 1024) a.grad[i] = 0.0f;
-    if (tid == 0) { a.stats[0] = 0.0f; a.stats[1] = 0.0f; }
+    if (i == 0) { a.report[0] = count; a.report[1] = count > 0.0f ? sq * inv : 0.0f; a.report[2] = norm; }
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -678,14 +800,24 @@ int pulse_qnet_forward(const PulseQNet* net, const float* states, int64_t row_st
 
 int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows, const int32_t* seat_idx,
                    int32_t q_seat, float epsilon, uint64_t seed, uint64_t step, uint64_t table_id0, int64_t* actions,
-                   float* q_out, void* stream) {
+                   float* q_out, const uint8_t* terminated, uint8_t* row_mask_out, void* stream) {
     if (!net || !actions) return pulse::fail(PULSE_EINVAL, "pulse_qnet_act: null argument");
+    if (row_mask_out && (!seat_idx || net->state_dim > 64))
+        return pulse::fail(PULSE_EINVAL, "pulse_qnet_act: row_mask_out needs seat_idx and state_dim <= 64");
     QNetArgs a{};
     a.net = *net; a.states = states; a.row_stride = row_stride; a.n_rows = n_rows; a.seat_idx = seat_idx; a.q_seat = q_seat;
     a.epsilon = epsilon; a.seed = seed; a.step = step; a.table_id0 = table_id0; a.actions = actions; a.q_out = q_out;
+    a.terminated = terminated; a.row_mask_out = row_mask_out;
     return launch(a, stream);
 }
 
+
+#if PULSE_STAMPS
+int pulse_debug_set_qnet_stamp_buffer(unsigned long long* buf) {
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_qstamp_buf), &buf, sizeof(buf));
+    return e == hipSuccess ? 0 : pulse::fail_hip((int)e, "pulse_debug_set_qnet_stamp_buffer");
+}
+#endif
 
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions) {
     if (state_dim < 1 || n_actions < 1 || n_actions > 32) return pulse::fail(PULSE_EINVAL, "pulse_qnet_param_count: bad dimensions");
@@ -695,7 +827,7 @@ int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions) {
 int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
-                          void* stream) {
+                          uint8_t* terminated, double* reward_sum, void* stream) {
     if (!t || !states || !actions || !rewards || !next_states || !dones)
         return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: null argument");
     const PulseQNet& n = t->net;
@@ -703,8 +835,9 @@ int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t 
         return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: state_dim must be 13..64 (column 12 is the seat status) and n_actions 1..32");
     if (t->target.state_dim != n.state_dim || t->target.n_actions != n.n_actions)
         return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: target network shape differs");
-    if (!t->params || !t->target_params || !t->grad || !t->exp_avg || !t->exp_avg_sq || !t->step || !t->stats || !t->report)
+    if (!t->params || !t->target_params || !t->grad || !t->exp_avg || !t->exp_avg_sq || !t->step || !t->stats || !t->report || !t->partials)
         return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: null optimizer buffer");
+    if (t->max_blocks < 1) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: max_blocks < 1");
     const int np = pulse_qnet_param_count(n.state_dim, n.n_actions);
     // the ten tensors of each network must be the views of the flat buffers in the documented order
     const float* expect = t->params; const float* expect_t = t->target_params;
@@ -723,30 +856,34 @@ int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t 
     if (!(t->dropout_p >= 0.0f && t->dropout_p < 1.0f)) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: dropout_p outside [0, 1)");
     if (n_rows < 0) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: n_rows < 0");
     hipStream_t st = (hipStream_t)stream;
-    if (n_rows > 0) {
-        TrainArgs a{};
-        a.net = t->net; a.tgt = t->target; a.grad = t->grad; a.stats = t->stats; a.states = states; a.stride = row_stride;
-        a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
-        a.row_mask = row_mask; a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
-        a.gamma = t->gamma; a.drop_p = t->dropout_p;
-        const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
-            if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
-            attr_set = true;
-        }
-        // one workgroup (4 wavefronts, 149 KB of LDS) per 256 candidate rows: a CU per tile of 32 valid rows
-        const unsigned grid = (unsigned)((n_rows + 255) / 256);
-        if (vec) hipLaunchKernelGGL((qnet_train_kernel<true>), dim3(grid), dim3(256), kTrainLdsBytes, st, a);
-        else hipLaunchKernelGGL((qnet_train_kernel<false>), dim3(grid), dim3(256), kTrainLdsBytes, st, a);
+    if (n_rows == 0) return 0;
+    TrainArgs a{};
+    a.net = t->net; a.tgt = t->target; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
+    a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
+    a.row_mask = row_mask; a.terminated = terminated; a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
+    a.gamma = t->gamma; a.drop_p = t->dropout_p;
+    const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
+        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
+        attr_set = true;
     }
+    // persistent workgroups (4 wavefronts, 149 KB of LDS: one per CU) striding over the 256-row windows
+    const int grid = std::min((n_rows + 255) / 256, (int)t->max_blocks);
+    if (vec) hipLaunchKernelGGL((qnet_train_kernel<true>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
+    else hipLaunchKernelGGL((qnet_train_kernel<false>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
+    ReduceArgs r{};
+    r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.grad = t->grad; r.scal = t->stats; r.step = (long long*)t->step;
+    r.reward_sum = reward_sum;
+    const unsigned eg = (unsigned)((np + 255) / 256);
+    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(eg), dim3(256), 0, st, r);
     AdamArgs b{};
-    b.params = t->params; b.target = t->target_params; b.grad = t->grad; b.m = t->exp_avg; b.v = t->exp_avg_sq; b.step = (long long*)t->step;
-    b.stats = t->stats; b.report = t->report; b.n_params = np; b.lr = t->lr; b.wd = t->weight_decay; b.beta1 = t->beta1; b.beta2 = t->beta2;
+    b.params = t->params; b.target = t->target_params; b.grad = t->grad; b.m = t->exp_avg; b.v = t->exp_avg_sq; b.step = (const long long*)t->step;
+    b.scal = t->stats; b.report = t->report; b.n_params = np; b.lr = t->lr; b.wd = t->weight_decay; b.beta1 = t->beta1; b.beta2 = t->beta2;
     b.eps = t->eps; b.max_norm = t->max_grad_norm; b.update_freq = t->update_freq;
-    hipLaunchKernelGGL(qnet_adamw_kernel, dim3(1), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(qnet_adamw_kernel, dim3(eg), dim3(256), 0, st, b);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : pulse::fail_hip((int)e, "pulse_qnet_train_step launch");
 }

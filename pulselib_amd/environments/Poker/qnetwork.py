@@ -7,7 +7,7 @@ What is native here:
     MFMA kernel (csrc/qnet.hip) reading the module's own weight tensors; no mask gather / scatter, no
     host sync, draws keyed by (seed, global table id, step) like the scripted opponents';
   * `train_step_native`: the whole update -- row filter, forward in train mode, TD target, backward, gradient
-    clipping, AdamW, target sync -- as two launches of csrc/qnet.hip with no host sync (the reference's boolean
+    clipping, AdamW, target sync -- as three launches of csrc/qnet.hip with no host sync (the reference's boolean
     indexing costs a device->host sync per mask);
   * `train_step_masked`: the same sync-free contract on PyTorch-ROCm autograd (every row goes through with a 0/1
     weight), kept as the torch cross-check of the native path.
@@ -24,6 +24,7 @@ import torch.nn as nn
 from ... import _native
 
 HIDDEN = (128, 128, 64, 32)      # Player.py:189-201
+TRAIN_BLOCKS = 256               # persistent workgroups of the training kernel: one per CU of an MI355X
 
 
 def build_network(state_dim: int, action_dim: int) -> nn.Sequential:
@@ -123,13 +124,14 @@ class PokerQNetwork(nn.Module):
         net = self._net_struct(self.network)
         _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), states.shape[0], None, 0,
                                                    float(self.epsilon), self.seed & (2**64 - 1), (1 << 40) + self._calls,
-                                                   self.table_id0, actions.data_ptr(), None,
+                                                   self.table_id0, actions.data_ptr(), None, None, None,
                                                    _native.current_stream(states.device)), "pulse_qnet_act")
         return actions
 
-    def act_into(self, states, curr_players, q_seat: int, actions, step_counter=None):
+    def act_into(self, states, curr_players, q_seat: int, actions, step_counter=None, terminated=None, row_mask_out=None):
         """`actions[mask] = self.get_actions(states[mask])` for mask = (curr_players == q_seat) (utils.py:113-119) as one
-        launch: rows of other seats are not touched, nothing is gathered, nothing syncs."""
+        launch: rows of other seats are not touched, nothing is gathered, nothing syncs.  `row_mask_out` (bool/uint8[n]):
+        also receives `(curr_players == q_seat) & ~terminated` for every row, the trainer's mask (trainGPU.py:85)."""
         self._decay_epsilon()
         states = self._rows(states)
         if actions.dtype != torch.int64 or not actions.is_contiguous():
@@ -141,6 +143,8 @@ class PokerQNetwork(nn.Module):
         _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), states.shape[0],
                                                    curr.data_ptr(), int(q_seat), float(self.epsilon), self.seed & (2**64 - 1), step,
                                                    self.table_id0, actions.data_ptr(), None,
+                                                   None if terminated is None else terminated.data_ptr(),
+                                                   None if row_mask_out is None else row_mask_out.data_ptr(),
                                                    _native.current_stream(states.device)), "pulse_qnet_act")
         return actions
 
@@ -172,24 +176,29 @@ class PokerQNetwork(nn.Module):
                 "m": torch.zeros(n, dtype=torch.float32, device=dev),
                 "v": torch.zeros(n, dtype=torch.float32, device=dev),
                 "step": torch.zeros(1, dtype=torch.int64, device=dev),
-                "stats": torch.zeros(2, dtype=torch.float32, device=dev),
+                "stats": torch.zeros(4, dtype=torch.float32, device=dev),
                 "report": torch.zeros(4, dtype=torch.float32, device=dev),
+                "partials": torch.empty(TRAIN_BLOCKS * (n + 4), dtype=torch.float32, device=dev),   # 33 MB at 256 workgroups
             }
         t = _native.QNetTrain()
         t.net, t.target = self._net_struct(self.network), self._net_struct(self.target_network)
         t.params, t.target_params = self._flat.data_ptr(), self._flat_target.data_ptr()
         t.grad, t.exp_avg, t.exp_avg_sq = nat["grad"].data_ptr(), nat["m"].data_ptr(), nat["v"].data_ptr()
         t.step, t.stats, t.report = nat["step"].data_ptr(), nat["stats"].data_ptr(), nat["report"].data_ptr()
+        t.partials, t.max_blocks = nat["partials"].data_ptr(), TRAIN_BLOCKS
         t.lr, t.weight_decay, t.beta1, t.beta2, t.eps = self.lr, self.wd, 0.9, 0.999, 1e-8       # torch.optim.AdamW defaults (:296)
         t.max_grad_norm, t.gamma = 1.0, float(self.gamma)                                      # clip_grad_norm_ (:280)
         t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
         t.update_freq = int(self.update_freq)
         return t
 
-    def train_step_native(self, states, actions, rewards, next_states, dones, row_mask=None, step_counter=None):
-        """train_step (Player.py:255-294) as two launches on the env's stream and no host sync: row filter
-        (row_mask & seat status ACTIVE/ALLIN) + TD target + forward + backward on the matrix cores -> gradient mean,
-        clip_grad_norm_, AdamW, target sync every update_freq optimizer steps.  Returns the device tensor
+    def train_step_native(self, states, actions, rewards, next_states, dones, row_mask=None, step_counter=None, terminated=None,
+                          reward_sum=None):
+        """train_step (Player.py:255-294) as three launches on the env's stream and no host sync: row filter
+        (row_mask & seat status ACTIVE/ALLIN) + TD target + forward + backward on the matrix cores -> reduction of the
+        workgroups' gradient slices -> gradient mean, clip_grad_norm_, AdamW, target sync every update_freq optimizer
+        steps.  `terminated` (bool[n], |= dones) and `reward_sum` (float64 scalar, += rewards over row_mask) fold the
+        trainer's per-step bookkeeping (scripts/Poker/trainGPU.py:86,96) into the same launches.  Returns the device tensor
         [rows trained on, MSE loss, gradient norm before clipping, 0] of this call (read it later, or never).
         Moments live in this path's own buffers (not in self.optimizer, which serves the torch train_step)."""
         states, next_states = self._rows(states), self._rows(next_states)
@@ -205,6 +214,13 @@ class PokerQNetwork(nn.Module):
                 x = x.to(torch.uint8).contiguous()
             return x
         dones8, mask8 = u8(dones), u8(row_mask)
+        term8 = None
+        if terminated is not None:           # trainer bookkeeping folded into the launch: terminated |= dones, reward_sum += ...
+            if terminated.dtype not in (torch.bool, torch.uint8) or not terminated.is_contiguous():
+                raise ValueError("terminated must be a contiguous bool / uint8 tensor (it is updated in place)")
+            term8 = terminated.data_ptr()
+        if reward_sum is not None and (reward_sum.dtype != torch.float64 or reward_sum.numel() != 1):
+            raise ValueError("reward_sum must be a float64 scalar tensor (it is accumulated in place)")
         if actions.dtype != torch.int64 or not actions.is_contiguous():
             actions = actions.to(torch.int64).contiguous()
         if rewards.dtype != torch.float32 or not rewards.is_contiguous():
@@ -214,7 +230,8 @@ class PokerQNetwork(nn.Module):
         _native.check(_native.lib().pulse_qnet_train_step(
             C.byref(t), states.data_ptr(), states.stride(0), actions.data_ptr(), rewards.data_ptr(), next_states.data_ptr(),
             next_states.stride(0), dones8.data_ptr(), None if mask8 is None else mask8.data_ptr(), n, self.seed & (2**64 - 1), step,
-            self.table_id0, _native.current_stream(states.device)), "pulse_qnet_train_step")
+            self.table_id0, term8, None if reward_sum is None else reward_sum.data_ptr(),
+            _native.current_stream(states.device)), "pulse_qnet_train_step")
         self.step_count += 1             # calls; the optimizer-step count (calls with at least one valid row) is native_steps()
         return self._native["report"]
 

@@ -111,12 +111,13 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     q_agent = agents[q_agent_idx]
     if not (hasattr(q_agent, "act_into") and hasattr(q_agent, "train_step_masked") and hasattr(q_agent, "train_step_native")):
         raise TypeError("train_agent_fused needs a learner with act_into / train_step_native (PokerQNetwork)")
-    learn = q_agent.train_step_native if learner == "native" else q_agent.train_step_masked
+    native = learner == "native"
     host_rng = random.Random(host_seed)
     done_count = LaggedDoneCount(device, n_games, TERMINATION_THRESHOLD)
     actions = torch.zeros(n_games, dtype=torch.long, device=device)
     state_before = torch.empty((n_games, env.obs_size), dtype=torch.float32, device=device)
     terminated = torch.zeros(n_games, dtype=torch.bool, device=device)
+    active_games = torch.zeros(n_games, dtype=torch.bool, device=device)
     episode_reward = torch.zeros((), dtype=torch.float64, device=device)
     stats = EpisodeStats(device)
     total_steps, global_step = 0, 0
@@ -124,7 +125,7 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     start_time = time.time()
     for episode in range(episodes):
         _, rotated_types, q_seat, rotations = get_rotated_agents(agents, agent_types, episode_idx=episode, q_agent_idx=q_agent_idx)
-        native = native_types(rotated_types)                     # the learner's seat is EXTERNAL: its action is taken as given
+        native_seats = native_types(rotated_types)               # the learner's seat is EXTERNAL: its action is taken as given
         A = host_rng.randint(2, env.n_players)
         state, info = env.reset(options={"rotation": rotations, "active_players": int(A), "q_agent_seat": q_seat})
         initial_stacks = info["stacks"][:, q_seat].clone()
@@ -134,14 +135,22 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         idx = 0
         while True:
             seat_idx = info["seat_idx"]
-            q_mask = seat_idx == q_seat
-            active_games = q_mask & ~terminated                                       # trainGPU.py:85, before the step
             state_before.copy_(state)                                                 # the env reuses its obs buffer
-            q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step)
-            next_state, rewards, dones, _, info = env.policy_step(native, actions, global_step)
-            terminated |= dones                                                       # :86
-            learn(state_before, actions, rewards, next_state, dones, active_games)
-            episode_reward += (rewards * active_games).sum()                          # :96
+            if native:
+                # active_games = q_mask & ~terminated (trainGPU.py:85) comes out of the act launch; `terminated |= dones`
+                # (:86) and the episode reward (:96) ride on the training launches
+                q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step, terminated=terminated,
+                                 row_mask_out=active_games)
+                next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
+                q_agent.train_step_native(state_before, actions, rewards, next_state, dones, active_games, step_counter=global_step,
+                                          terminated=terminated, reward_sum=episode_reward)
+            else:
+                torch.logical_and(seat_idx == q_seat, ~terminated, out=active_games)      # :85, before the step
+                q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step)
+                next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
+                terminated |= dones                                                   # :86
+                q_agent.train_step_masked(state_before, actions, rewards, next_state, dones, active_games)
+                episode_reward += (rewards * active_games).sum()                      # :96
             if step_hook is not None:
                 step_hook(episode, idx, state_before, actions, rewards, next_state, dones, active_games)
             state = next_state

@@ -75,10 +75,13 @@ def test_hip_act_matches_oracle_and_leaves_other_seats_alone(g, eps):
     seat[192:256] = 4
     actions = torch.full((n,), -5, dtype=torch.long, device=DEV)
     qrows = torch.zeros((n, 13), device=DEV)
+    term = torch.from_numpy(rng.random(n) < 0.25).to(DEV)
+    mask = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
     net = q._net_struct(q.network)
     _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), 40, n, seat.data_ptr(), 3, eps, 4242, 77,
-                                               10_000_000_000, actions.data_ptr(), qrows.data_ptr(),
+                                               10_000_000_000, actions.data_ptr(), qrows.data_ptr(), term.data_ptr(), mask.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), "pulse_qnet_act")
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), (seat.cpu().numpy() == 3) & ~term.cpu().numpy().astype(bool))
     sel = seat.cpu().numpy() == 3
     got = actions.cpu().numpy()
     assert (got[~sel] == -5).all() and sel.sum() > 400
@@ -269,7 +272,7 @@ def test_native_gradient_matches_oracle_and_torch_autograd(g):
     _native.check(_native.lib().pulse_qnet_train_step(C.byref(t), dev["states"].data_ptr(), 40, dev["actions"].data_ptr(),
                                                       dev["rewards"].data_ptr(), dev["next_states"].data_ptr(), 40,
                                                       dev["dones"].view(torch.uint8).data_ptr(), dev["row_mask"].view(torch.uint8).data_ptr(),
-                                                      n, 5, 1, 0, torch.cuda.current_stream().cuda_stream), "pulse_qnet_train_step")
+                                                      n, 5, 1, 0, None, None, torch.cuda.current_stream().cuda_stream), "pulse_qnet_train_step")
     rep = nat["report"].cpu().numpy()
     grad, cnt, sq = orc.qnet_train_grads(p0, p0, b["states"], b["actions"], b["rewards"], b["next_states"], b["dones"], b["row_mask"],
                                          0.95, 0.0, 5, 1, 0)
@@ -306,3 +309,19 @@ def test_native_training_reduces_td_error_on_a_fixed_batch(g):
         if it % 50 == 0 or it == 199:
             losses.append(float(rep[1]))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_native_train_step_folds_trainer_bookkeeping(g):
+    """terminated |= dones and reward_sum += rewards[row_mask] ride along with the training launches (trainGPU.py:86,96)."""
+    q = _qnet(g, "s40", seed=2)
+    n = 5000
+    b = _batch(n, 11)
+    dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
+    term = torch.from_numpy(np.random.default_rng(3).random(n) < 0.2).to(DEV)
+    want_term = (term | dev["dones"]).cpu().numpy()
+    acc = torch.full((), 10.0, dtype=torch.float64, device=DEV)
+    q.train_step_native(dev["states"], dev["actions"], dev["rewards"], dev["next_states"], dev["dones"], dev["row_mask"],
+                        terminated=term, reward_sum=acc)
+    np.testing.assert_array_equal(term.cpu().numpy(), want_term)
+    want = 10.0 + float(b["rewards"][b["row_mask"]].astype(np.float64).sum())
+    assert abs(float(acc) - want) < 1e-3 * max(1.0, abs(want))
