@@ -54,3 +54,17 @@ out = {
 json.dump(out, open(dst / "step_kernel_profile.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("rocprof_kernel_trace", "bench_event_chunk_avg_us", "traffic_bytes_per_launch",
                                       "algorithmic_bytes_per_launch")}, indent=1))
+
+# trainer loop (learner in the loop): kernel-trace stats of the same command + the plain lines
+tr = glob.glob(str(src / "trainer" / "*" / "*kernel_stats.csv"))
+if tr:
+    shutil.copy(tr[0], dst / "trainer_kernel_stats.csv")
+    lines = {}
+    for name in ("trainer_plain", "trainer_reference_loop", "trainer_torch_learner"):
+        f = src / f"{name}.log"
+        if f.exists():
+            last = [ln for ln in f.read_text().splitlines() if ln.startswith("{")]
+            if last:
+                lines[name] = json.loads(last[-1])
+    json.dump(lines, open(dst / "trainer_lines.json", "w"), indent=1)
+    print({k: round(v["value"] / 1e6, 1) for k, v in lines.items()}, "M env-steps/s")
