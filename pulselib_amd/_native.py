@@ -121,6 +121,9 @@ def lib() -> C.CDLL:
             if os.environ.get("PULSE_NO_AUTOBUILD"):
                 raise PulseError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
             build()
+        # PyTorch-ROCm ships its own libamdhip64; it must be in the process before this library resolves its HIP
+        # dependency, or two HIP runtimes coexist and launches on torch's tensors fail ("no ROCm-capable device")
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(str(_SO))
         except OSError as e:  # pragma: no cover - environment specific
