@@ -176,6 +176,16 @@ int pulse_calib_stream(int32_t* buf, uint64_t n_words, int32_t write, void* stre
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n,
                       int64_t* stats, double* fstats, void* stream);
 
+/* Hand-level metrics side-channel (scripts/Poker/trainGPU_performance.py:198-206, utils/performance.py): for every
+ * table with dones[t] && !terminated_before[t] (NULL = none terminated) the learner seat's chip delta
+ * stacks[t][q_seat] - initial_q_stacks[t] is added to acc[position][bucket][4] = {hands, wins, sum delta, sum delta^2}
+ * (device int64[16*5*4], zeroed by the caller when a new aggregation starts); position = (q_seat - button[t]) mod
+ * active_players, bucket = clamp(stages[t], 0, 4).  No host sync; BB/100, win rates by street / position and the
+ * confidence bound follow from the sums on the host (pulselib_amd/utils/performance.py). */
+int pulse_poker_hand_metrics(const uint8_t* dones, const uint8_t* terminated_before, const int32_t* stacks, int32_t n_players,
+                             const int32_t* initial_q_stacks, const int32_t* stages, const int32_t* button, int32_t q_seat,
+                             int32_t active_players, int32_t n, int64_t* acc, void* stream);
+
 /* ---- Blackjack (environments/blackjack/blackjack.py) ------------------------------------------ */
 typedef struct PulseBlackjackView {
     int32_t batch_size;

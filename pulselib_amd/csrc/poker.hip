@@ -888,6 +888,38 @@ __global__ __launch_bounds__(kBlock) void poker_stats_kernel(const uint8_t* __re
     }
 }
 
+// ---------------------------------------------------------------- hand metrics side-channel
+// What scripts/Poker/trainGPU_performance.py:198-206 gathers per step with boolean indexing (a device->host sync each:
+// `newly_done.any()`, stacks[newly_done, q_seat], stages[newly_done], positions[newly_done]) as sufficient statistics
+// kept on the device: for every hand that finished in this step (done and not terminated before), its chip delta for
+// the learner's seat is added to acc[position][street bucket] = {hands, wins (delta > 0), sum delta, sum delta^2}
+// (int64: deltas are whole chips, the sums are exact).  position = (q_seat - button) mod A (utils/performance.py:55-59),
+// bucket = min(stage, 4) with negatives clamped to 0 (:170-173).  LDS histogram per workgroup, then one atomic per
+// touched cell.
+__global__ __launch_bounds__(kBlock) void poker_hand_metrics_kernel(const uint8_t* __restrict__ dones, const uint8_t* __restrict__ terminated_before,
+                                                                   const int32_t* __restrict__ stacks, int n_players,
+                                                                   const int32_t* __restrict__ initial_q_stacks, const int32_t* __restrict__ stages,
+                                                                   const int32_t* __restrict__ button, int q_seat, int active_players, int n,
+                                                                   unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long h[PULSE_MAX_SEATS * 5 * 4];
+    for (int i = threadIdx.x; i < PULSE_MAX_SEATS * 5 * 4; i += kBlock) h[i] = 0ull;
+    __syncthreads();
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
+        if (!dones[t] || (terminated_before && terminated_before[t])) continue;
+        const long long delta = (long long)stacks[(size_t)t * n_players + q_seat] - (long long)initial_q_stacks[t];
+        const int pos = pymod(q_seat - button[t], active_players);
+        const int st = stages[t], bucket = st >= 4 ? 4 : max(st, 0);
+        unsigned long long* cell = h + ((pos & (PULSE_MAX_SEATS - 1)) * 5 + bucket) * 4;
+        atomicAdd(cell + 0, 1ull);
+        if (delta > 0) atomicAdd(cell + 1, 1ull);
+        atomicAdd(cell + 2, (unsigned long long)delta);                       // two's complement: signed sums wrap correctly
+        atomicAdd(cell + 3, (unsigned long long)(delta * delta));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PULSE_MAX_SEATS * 5 * 4; i += kBlock)
+        if (h[i] != 0ull) atomicAdd(acc + i, h[i]);
+}
+
 // ---------------------------------------------------------------- PMC calibration (diagnostic)
 // Streams `n_words` dwords with this library's access shape -- one dword per lane, lanes on consecutive
 // addresses -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count
@@ -1156,6 +1188,20 @@ int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_
     hipLaunchKernelGGL(poker_stats_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, is_done, rewards, mask, n,
                        reinterpret_cast<unsigned long long*>(stats), fstats);
     return finish_launch("pulse_poker_stats");
+}
+
+int pulse_poker_hand_metrics(const uint8_t* dones, const uint8_t* terminated_before, const int32_t* stacks, int32_t n_players,
+                             const int32_t* initial_q_stacks, const int32_t* stages, const int32_t* button, int32_t q_seat,
+                             int32_t active_players, int32_t n, int64_t* acc, void* stream) {
+    if (!dones || !stacks || !initial_q_stacks || !stages || !button || !acc || n < 0)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_hand_metrics: null argument");
+    if (n_players < 2 || n_players > PULSE_MAX_SEATS || active_players < 2 || active_players > n_players || q_seat < 0 || q_seat >= n_players)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_hand_metrics: need 2 <= active_players <= n_players <= 16 and 0 <= q_seat < n_players");
+    if (n == 0) return 0;
+    const int grid = min(256, (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(poker_hand_metrics_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, dones, terminated_before, stacks,
+                       n_players, initial_q_stacks, stages, button, q_seat, active_players, n, reinterpret_cast<unsigned long long*>(acc));
+    return finish_launch("pulse_poker_hand_metrics");
 }
 
 }  // extern "C"

@@ -7,9 +7,8 @@
     (trainGPU.py:108) -- finished tables count, as in every number the reference publishes;
   * run summary with the reference's keys (`sps`, `total_steps`, ...; utils/benchmarking/benchmarking.py:84-100).
 
-The learner is whatever object sits at the QLEARNING seat (`get_actions`, `train_step`): the reference's
-PokerQNetwork runs unchanged on PyTorch-ROCm; `SimpleQNetwork` below is a minimal stand-in with the same
-interface.  With N > 1 ranks each process drives its own shard and episode sums are all-reduced (RCCL)."""
+The learner is whatever object sits at the QLEARNING seat (`get_actions`, `train_step`); ours is
+environments/Poker/qnetwork.py: PokerQNetwork, whose native kernels `train_agent_fused` drives without host syncs.  With N > 1 ranks each process drives its own shard and episode sums are all-reduced (RCCL)."""
 from __future__ import annotations
 
 import time
@@ -93,7 +92,7 @@ def train_agent(env, agents, agent_types, episodes, n_games, device, results_dir
 
 def train_agent_fused(env, agents, agent_types, episodes, n_games, device, results_dir=None, config=None, plotter=None,
                       benchmarker=None, max_episode_steps=None, reduce_stats=True, stop_rule="lagged", host_seed=0,
-                      step_hook=None, learner="native"):
+                      step_hook=None, learner="native", hand_metrics=None):
     """train_agent with nothing in the step waiting on the host: the loop contract above (rotation, masks evaluated
     before `terminated |= dones`, stop cadence, step accounting) on four launches-groups per step --
       learner's actions (pulse_qnet_act, masked by seat) -> scripted opponents + env step (pulse_poker_policy_step) ->
@@ -101,7 +100,9 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
       PyTorch autograd) -> every 5th step the lagged done-count.
     `active_players` is drawn from a host RNG (the reference reads a device randint back, PokerGPU.py:76-77) and the
     stop rule is decided on the newest count that already reached the host (stoprule.py); `stop_rule="sync"`
-    restores the reference's blocking check.  Needs a learner with `act_into` / `train_step_masked` (qnetwork.py)."""
+    restores the reference's blocking check.  Needs a learner with `act_into` / `train_step_masked` (qnetwork.py).
+    `hand_metrics` (utils.performance.HandMetrics) adds the BB/100 side-channel of trainGPU_performance.py:192-206 as
+    one more launch per step; its per-episode summaries come back under "hand_metrics"."""
     import random
 
     from ..environments.Poker.utils import native_types
@@ -121,7 +122,7 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     episode_reward = torch.zeros((), dtype=torch.float64, device=device)
     stats = EpisodeStats(device)
     total_steps, global_step = 0, 0
-    scores, reward_scores = [], []
+    scores, reward_scores, episode_metrics = [], [], []
     start_time = time.time()
     for episode in range(episodes):
         _, rotated_types, q_seat, rotations = get_rotated_agents(agents, agent_types, episode_idx=episode, q_agent_idx=q_agent_idx)
@@ -132,6 +133,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         terminated.zero_()
         episode_reward.zero_()
         done_count.drain()
+        if hand_metrics is not None:
+            hand_metrics.begin_episode(env, q_seat)
         idx = 0
         while True:
             seat_idx = info["seat_idx"]
@@ -142,12 +145,16 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
                 q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step, terminated=terminated,
                                  row_mask_out=active_games)
                 next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
+                if hand_metrics is not None:
+                    hand_metrics.update(env, dones, terminated)                       # before terminated |= dones
                 q_agent.train_step_native(state_before, actions, rewards, next_state, dones, active_games, step_counter=global_step,
                                           terminated=terminated, reward_sum=episode_reward)
             else:
                 torch.logical_and(seat_idx == q_seat, ~terminated, out=active_games)      # :85, before the step
                 q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step)
                 next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
+                if hand_metrics is not None:
+                    hand_metrics.update(env, dones, terminated)
                 terminated |= dones                                                   # :86
                 q_agent.train_step_masked(state_before, actions, rewards, next_state, dones, active_games)
                 episode_reward += (rewards * active_games).sum()                      # :96
@@ -168,6 +175,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         host = totals.cpu()                                                           # one read-back per episode
         reward_scores.append(float(host[1]))
         scores.append(float(host[2]))
+        if hand_metrics is not None:
+            episode_metrics.append(hand_metrics.end_episode())
         total_steps += n_games * idx                                                  # :108
 
     torch.cuda.synchronize(device)
@@ -176,6 +185,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     summary = {"env": config.get("ENV_ID", "Pulse-Poker-GPU-v1"), "total_steps": total_steps, "start_time": start_time,
                "end_time": end_time, "total_training_seconds": elapsed, "sps": total_steps / elapsed if elapsed > 0 else 0.0,
                "episode_rewards": reward_scores, "episode_profits": scores, "config": dict(config), "env_step_calls": global_step}
+    if hand_metrics is not None:
+        summary["hand_metrics"] = {"episodes": episode_metrics, "final": hand_metrics.summary()}
     if plotter is not None and results_dir is not None:
         plotter.plot_learning_curve(scores=reward_scores, file_path=str(Path(results_dir) / "rewards_learning_curve"), window_size=10,
                                     title="Poker Q-Learning - Total Reward per Episode Batch")
@@ -187,55 +198,46 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     return summary
 
 
-class SimpleQNetwork(torch.nn.Module):
-    """Minimal learner with the interface the driver needs (the reference's PokerQNetwork,
-    environments/Poker/Player.py:178-298, is the real one and runs unchanged on PyTorch-ROCm)."""
+def main(argv=None):
+    """python -m pulselib_amd.scripts.trainGPU [--tables N] [--episodes E] [--results DIR]: the reference's
+    scripts/Poker/trainGPU.py:148-214 on the fused loop -- PokerQNetwork + the config's opponents, run summary written
+    as results/PokerGPU/runs/run_N.yaml (utils/benchmarking.py) and the final weights as poker_qnet_final.pth."""
+    import argparse
 
-    def __init__(self, device, gamma=0.95, state_dim=40, action_dim=13, lr=2e-4, epsilon=0.1):
-        super().__init__()
-        self.device, self.gamma, self.epsilon = device, gamma, epsilon
-        self.network = torch.nn.Sequential(torch.nn.Linear(state_dim, 128), torch.nn.GELU(), torch.nn.Linear(128, 64), torch.nn.GELU(),
-                                           torch.nn.Linear(64, action_dim)).to(device)
-        self.optimizer = torch.optim.AdamW(self.parameters(), lr=lr)
-
-    def get_actions(self, states):
-        with torch.inference_mode():
-            greedy = self.network(states).argmax(dim=1)
-            explore = torch.rand(states.shape[0], device=states.device) < self.epsilon
-            return torch.where(explore, torch.randint(0, 13, (states.shape[0],), device=states.device), greedy)
-
-    def train_step(self, states, actions, rewards, next_states, dones):
-        valid = (states[:, 12] == 0) | (states[:, 12] == 2)           # Player.py:261
-        if not valid.any():
-            return 0.0
-        states, actions, rewards, next_states, dones = states[valid], actions[valid], rewards[valid], next_states[valid], dones[valid]
-        q = self.network(states).gather(1, actions.unsqueeze(1)).squeeze(1)
-        with torch.no_grad():
-            target = rewards + self.gamma * self.network(next_states).max(dim=1).values * (~dones).float()
-        loss = torch.nn.functional.mse_loss(q, target)
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
-        self.optimizer.step()
-        return loss
-
-
-def main():
     import yaml
-    from ..environments.Poker import PokerGPU, load_gpu_agents
+
+    from ..environments.Poker import PokerGPU, PokerQNetwork, load_gpu_agents
+    from ..utils.benchmarking import YamlBenchmarker, result_folder_for
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tables", type=int, default=None)
+    ap.add_argument("--episodes", type=int, default=None)
+    ap.add_argument("--results", type=Path, default=Path.cwd() / "results")
+    args = ap.parse_args(argv)
     cfg = yaml.safe_load((Path(__file__).resolve().parent.parent / "config" / "pokerGPU.yaml").read_text())
     env_cfg, rew, learner = cfg["env"], cfg["reward"], cfg["learner"]
     device = torch.device("cuda", torch.cuda.current_device())
-    n_games = int(env_cfg["tables"])
+    n_games = int(args.tables or env_cfg["tables"])
+    episodes = int(args.episodes or cfg["run"]["episodes"])
     agents, types = load_gpu_agents(device, env_cfg["opponents"], list(cfg["opponent_mix"]), env_cfg["starting_stack_bb"], env_cfg["actions"])
-    agents.insert(0, SimpleQNetwork(device, gamma=learner["gamma"], state_dim=env_cfg["observation_size"], lr=float(learner["learning_rate"])))
+    results_dir = result_folder_for(env_cfg["id"], args.results)
+    q_net = PokerQNetwork(weights_path=results_dir / "poker_qnet_final.pth", device=device, gamma=learner["gamma"],
+                          update_freq=int(learner["target_update_every"]), state_dim=env_cfg["observation_size"],
+                          action_dim=env_cfg["actions"], learning_rate=float(learner["learning_rate"]),
+                          weight_decay=float(learner["weight_decay"]), seed=env_cfg.get("seed", 0))
+    agents.insert(0, q_net)
     types.insert(0, PokerAgentType.QLEARNING)
     env = PokerGPU(device=device, agents=agents, n_players=env_cfg["opponents"] + 1, n_games=n_games,
                    starting_bbs=env_cfg["starting_stack_bb"], w1=rew["w1"], w2=rew["w2"], K=rew["K"], alpha=rew["alpha"],
                    seed=env_cfg.get("seed", 0))
-    out = train_agent(env, agents, types, int(cfg["run"]["episodes"]), n_games, device, config={"ENV_ID": env_cfg["id"], **cfg["run"]},
-                      max_episode_steps=env_cfg.get("max_episode_steps"))
+    run_config = {"ENV_ID": env_cfg["id"], "N_GAMES": n_games, "EPISODES": episodes, "NUM_PLAYERS": env_cfg["opponents"],
+                  "AGENTS": list(cfg["opponent_mix"]), "GAMMA": learner["gamma"], "LEARNING_RATE": learner["learning_rate"],
+                  "WEIGHT_DECAY": learner["weight_decay"], "UPDATE_FREQ": learner["target_update_every"], **rew}
+    out = train_agent_fused(env, agents, types, episodes, n_games, device, results_dir=results_dir, config=run_config,
+                            benchmarker=YamlBenchmarker(results_dir_resolver=lambda env_name: results_dir),
+                            max_episode_steps=env_cfg.get("max_episode_steps"))
+    torch.save(q_net.network.state_dict(), results_dir / "poker_qnet_final.pth")          # trainGPU.py:118
     print({k: out[k] for k in ("total_steps", "total_training_seconds", "sps")})
+    return out
 
 
 if __name__ == "__main__":

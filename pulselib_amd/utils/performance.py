@@ -1,0 +1,116 @@
+"""Hand-level performance metrics without per-step host syncs.
+
+The reference's benchmark trainer (scripts/Poker/trainGPU_performance.py:198-206) pulls, on every step,
+`stacks[newly_done, q_seat]`, `stages[newly_done]` and the seat positions through boolean indexing -- a device->host
+sync each -- and keeps per-hand lists that utils/performance.py reduces at the end.  Every metric it reports except
+the rolling window is a function of per-group sums, so `HandMetrics` keeps exactly those on the device
+(pulse_poker_hand_metrics: hands, wins, sum delta, sum delta^2 per (button-relative position, street bucket), exact
+int64) and folds them into host totals per episode, keyed by the episode's player count.  Metric names and formulas
+follow utils/performance.py (cited per function); values are plain floats."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .. import _native
+
+STREET_DEPTH_NAMES = {0: "preflop", 1: "flop", 2: "turn", 3: "river", 4: "showdown"}     # utils/performance.py:8-14
+CONFIDENCE_Z_95 = 1.959963984540054                                                      # :15
+MAX_SEATS, BUCKETS = 16, 5
+
+
+def calculate_q_seat_positions(buttons: torch.Tensor, *, q_seat: int, active_players: int) -> torch.Tensor:
+    """Button-relative position of the learner's seat per table (utils/performance.py:55-59)."""
+    return torch.remainder(q_seat - buttons, active_players).to(torch.int64)
+
+
+def bb_per_100(count: int, total: float) -> float:
+    """mean big blinds won per 100 hands (:104-109)"""
+    return 100.0 * total / count if count else 0.0
+
+
+def lcb95_bb_per_100(count: int, total: float, total_sq: float) -> float:
+    """lower 95 % confidence bound of BB/100 with the population std (:112-125)"""
+    if count == 0:
+        return 0.0
+    mean = total / count
+    if count == 1:
+        return 100.0 * mean
+    var = max(total_sq / count - mean * mean, 0.0)
+    return 100.0 * (mean - CONFIDENCE_Z_95 * math.sqrt(var) / math.sqrt(count))
+
+
+class HandMetrics:
+    """Device accumulators for one run; `begin_episode` / `update` per step / `end_episode`, then `summary()`."""
+
+    def __init__(self, device, n_tables: int):
+        self.device, self.n = device, int(n_tables)
+        self.acc = torch.zeros(MAX_SEATS * BUCKETS * 4, dtype=torch.int64, device=device)
+        self.initial = torch.zeros(self.n, dtype=torch.int32, device=device)
+        self.totals = {}                     # player_count -> int64[16,5,4] on the host
+        self.q_seat, self.active_players = 0, 2
+        self._lib = _native.lib()
+
+    def begin_episode(self, env, q_seat: int) -> None:
+        """after env.reset: remember the learner's starting stacks (trainGPU_performance.py:165)"""
+        self.q_seat, self.active_players = int(q_seat), int(env.active_players)
+        self.initial.copy_(env.stacks[:, self.q_seat])
+        self.acc.zero_()
+
+    def update(self, env, dones: torch.Tensor, terminated_before: torch.Tensor | None) -> None:
+        """after env.step and BEFORE `terminated |= dones`: account the hands that finished in this step (:192-206)."""
+        d = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
+        t = None if terminated_before is None else (terminated_before.view(torch.uint8) if terminated_before.dtype == torch.bool
+                                                    else terminated_before)
+        _native.check(self._lib.pulse_poker_hand_metrics(
+            d.data_ptr(), None if t is None else t.data_ptr(), env.stacks.data_ptr(), env.n_players, self.initial.data_ptr(),
+            env.stages.data_ptr(), env.button.data_ptr(), self.q_seat, self.active_players, self.n, self.acc.data_ptr(),
+            torch.cuda.current_stream(self.device).cuda_stream), "pulse_poker_hand_metrics")
+
+    def end_episode(self) -> dict:
+        """One read-back per episode (at the point where the trainer reads its episode sums anyway); returns the
+        episode's summary with the keys of summarize_episode_performance_metrics (:138-167)."""
+        a = self.acc.cpu().numpy().reshape(MAX_SEATS, BUCKETS, 4).copy()
+        tot = self.totals.setdefault(self.active_players, np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64))
+        tot += a
+        hands, wins, total = int(a[..., 0].sum()), int(a[..., 1].sum()), float(a[..., 2].sum())
+        return {"mean_bb_delta": total / hands if hands else 0.0, "hand_win_rate": wins / hands if hands else 0.0,
+                "hands_completed": hands, "field_bb_per_100": bb_per_100(hands, total)}
+
+    def summary(self) -> dict:
+        """The hand-derived part of calculate_final_performance_metrics (:352-...): totals, BB/100 with its lower bound,
+        seat-balanced BB/100 (:242-253), win share by street (:176-196), win rate by position (:199-221) and the BB/100
+        slices by seat / player count / street depth (:256-318) with the worst slice (:321-349)."""
+        if not self.totals:
+            allt = np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64)
+        else:
+            allt = sum(self.totals.values())
+        hands, wins = int(allt[..., 0].sum()), int(allt[..., 1].sum())
+        total, total_sq = float(allt[..., 2].sum()), float(allt[..., 3].sum())
+        by_pos = allt.sum(axis=1)            # [16, 4]
+        by_street = allt.sum(axis=0)         # [5, 4]
+        seats = [p for p in range(MAX_SEATS) if by_pos[p, 0] > 0]
+        seat_slices = {f"position_{p}": bb_per_100(int(by_pos[p, 0]), float(by_pos[p, 2])) for p in seats}
+        slices = {
+            "seat": seat_slices,
+            "player_count": {f"players_{a}": bb_per_100(int(t[..., 0].sum()), float(t[..., 2].sum())) for a, t in sorted(self.totals.items())
+                             if t[..., 0].sum() > 0},
+            "street_depth": {STREET_DEPTH_NAMES[b]: bb_per_100(int(by_street[b, 0]), float(by_street[b, 2])) for b in range(BUCKETS)
+                             if by_street[b, 0] > 0},
+        }
+        worst = min(((v, fam, name) for fam, d in slices.items() for name, v in d.items()), default=(0.0, "", ""))
+        return {
+            "total_hands": hands,
+            "total_bb_won": total,
+            "overall_hand_win_rate": wins / hands if hands else 0.0,
+            "field_bb_per_100": bb_per_100(hands, total),
+            "lcb95_bb_per_100": lcb95_bb_per_100(hands, total, total_sq),
+            "seat_balanced_bb_per_100": float(np.mean(list(seat_slices.values()))) if seat_slices else 0.0,
+            "street_win_percentages": {STREET_DEPTH_NAMES[b]: (int(by_street[b, 1]) / hands if hands else 0.0) for b in range(BUCKETS)},
+            "position_win_rates": {f"position_{p}": {"hands": int(by_pos[p, 0]), "wins": int(by_pos[p, 1]),
+                                                     "win_rate": int(by_pos[p, 1]) / int(by_pos[p, 0])} for p in seats},
+            "slices": slices,
+            "worst_slice": {"bb_per_100": worst[0], "family": worst[1], "slice": worst[2]},
+        }

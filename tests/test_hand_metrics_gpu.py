@@ -1,0 +1,71 @@
+"""Hand-metrics side-channel: the on-device sums (pulse_poker_hand_metrics) reproduce what the reference's
+benchmark trainer collects per hand with boolean indexing (scripts/Poker/trainGPU_performance.py:192-206) and reduces with
+utils/performance.py -- restated here on the per-hand lists in numpy, formula by formula."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+Z95 = 1.959963984540054
+
+
+def test_hand_metrics_match_per_hand_lists():
+    from pulselib_amd.environments.Poker import PokerGPU
+    from pulselib_amd.utils.performance import HandMetrics, calculate_q_seat_positions
+    dev = torch.device(DEV)
+    N, P = 4096, 10
+    env = PokerGPU(device=dev, agents=[], n_players=P, max_players=P, n_games=N, seed=9)
+    hm = HandMetrics(dev, N)
+    rng = np.random.default_rng(4)
+    deltas, stages, positions, counts, episode_rows = [], [], [], [], []
+    for ep, (A, q_seat) in enumerate(((6, 2), (10, 7), (2, 1), (6, 0))):
+        _, info = env.reset(options={"active_players": A, "q_agent_seat": q_seat, "rotation": ep})
+        hm.begin_episode(env, q_seat)
+        initial = info["stacks"][:, q_seat].clone()
+        pos = calculate_q_seat_positions(env.button, q_seat=q_seat, active_players=env.active_players)
+        np.testing.assert_array_equal(pos.cpu().numpy(), (q_seat - env.button.cpu().numpy()) % env.active_players)
+        terminated = torch.zeros(N, dtype=torch.bool, device=dev)
+        ep_deltas = []
+        for step in range(45):
+            actions = torch.from_numpy(rng.choice(13, N, p=[.08, .5, .08, .03, .03, .03, .03, .03, .03, .02, .02, .02, .1])).to(dev)
+            _, _, dones, _, info = env.step(actions)
+            hm.update(env, dones, terminated)
+            newly = dones & ~terminated                                            # trainGPU_performance.py:192-195
+            terminated |= dones
+            if newly.any():                                                        # :198-206, the reference's way
+                d = (info["stacks"][newly, q_seat] - initial[newly]).cpu().numpy().astype(np.float64)
+                deltas.append(d); ep_deltas.append(d)
+                stages.append(env.stages[newly].cpu().numpy()); positions.append(pos[newly].cpu().numpy())
+                counts.append(np.full(d.size, env.active_players))
+        got = hm.end_episode()
+        e = np.concatenate(ep_deltas)
+        assert got["hands_completed"] == e.size
+        assert abs(got["mean_bb_delta"] - e.mean()) < 1e-9 and abs(got["hand_win_rate"] - (e > 0).mean()) < 1e-12
+        assert abs(got["field_bb_per_100"] - 100 * e.mean()) < 1e-7
+    d = np.concatenate(deltas); st = np.concatenate(stages); po = np.concatenate(positions); pc = np.concatenate(counts)
+    bucket = np.where(st >= 4, 4, np.clip(st, 0, 3))                               # utils/performance.py:170-173
+    s = hm.summary()
+    assert s["total_hands"] == d.size and s["total_bb_won"] == d.sum()
+    assert abs(s["overall_hand_win_rate"] - (d > 0).mean()) < 1e-12
+    assert abs(s["field_bb_per_100"] - 100 * d.mean()) < 1e-7                       # :104-109
+    lcb = 100 * (d.mean() - Z95 * d.std() / np.sqrt(d.size))                       # :112-125 (population std)
+    assert abs(s["lcb95_bb_per_100"] - lcb) < 1e-6
+    names = {0: "preflop", 1: "flop", 2: "turn", 3: "river", 4: "showdown"}
+    for b, name in names.items():                                                  # :176-196
+        assert abs(s["street_win_percentages"][name] - ((d > 0) & (bucket == b)).sum() / d.size) < 1e-12
+    seat_vals = []
+    for p in np.unique(po):                                                        # :199-221, :242-253
+        m = po == p
+        r = s["position_win_rates"][f"position_{p}"]
+        assert r["hands"] == m.sum() and r["wins"] == (d[m] > 0).sum() and abs(r["win_rate"] - (d[m] > 0).mean()) < 1e-12
+        assert abs(s["slices"]["seat"][f"position_{p}"] - 100 * d[m].mean()) < 1e-7
+        seat_vals.append(100 * d[m].mean())
+    assert set(s["position_win_rates"]) == {f"position_{p}" for p in np.unique(po)}
+    assert abs(s["seat_balanced_bb_per_100"] - np.mean(seat_vals)) < 1e-7
+    for a in np.unique(pc):                                                        # :256-318
+        assert abs(s["slices"]["player_count"][f"players_{a}"] - 100 * d[pc == a].mean()) < 1e-7
+    for b in np.unique(bucket):
+        assert abs(s["slices"]["street_depth"][names[b]] - 100 * d[bucket == b].mean()) < 1e-7
+    allv = [v for fam in s["slices"].values() for v in fam.values()]
+    assert s["worst_slice"]["bb_per_100"] == min(allv)                             # :321-349

@@ -325,3 +325,38 @@ def test_native_train_step_folds_trainer_bookkeeping(g):
     np.testing.assert_array_equal(term.cpu().numpy(), want_term)
     want = 10.0 + float(b["rewards"][b["row_mask"]].astype(np.float64).sum())
     assert abs(float(acc) - want) < 1e-3 * max(1.0, abs(want))
+
+
+def test_trainer_entry_point_writes_run_summary_and_weights(tmp_path):
+    """python -m pulselib_amd.scripts.trainGPU: fused loop + run_N.yaml with the reference writer's keys + the final
+    weights (scripts/Poker/trainGPU.py:118), which load back into the reference's Sequential layout."""
+    import yaml
+    from pulselib_amd.environments.Poker.qnetwork import build_network
+    from pulselib_amd.scripts.trainGPU import main
+    out = main(["--tables", "2048", "--episodes", "2", "--results", str(tmp_path)])
+    run = tmp_path / "PokerGPU" / "runs" / "run_1.yaml"
+    d = yaml.safe_load(run.read_text())
+    assert d["env"] == "Pulse-Poker-GPU-v1" and d["total_steps"] == out["total_steps"] > 0 and d["sps"] > 0
+    assert d["episode_stats"]["count"] == 2 and d["config"]["N_GAMES"] == 2048
+    sd = torch.load(tmp_path / "PokerGPU" / "poker_qnet_final.pth", weights_only=True)
+    build_network(40, 13).load_state_dict(sd)
+
+
+def test_fused_trainer_with_hand_metrics_side_channel(g):
+    from pulselib_amd.environments.Poker import PokerGPU, load_gpu_agents
+    from pulselib_amd.environments.Poker.utils import PokerAgentType
+    from pulselib_amd.scripts.trainGPU import train_agent_fused
+    from pulselib_amd.utils.performance import HandMetrics
+    dev = torch.device(DEV)
+    agents, types = load_gpu_agents(dev, 5, ["tight_aggressive", "heuristic_hands", "loose_passive", "random", "small_ball"], 100, 13)
+    agents.insert(0, _qnet(g, "s40", seed=3))
+    types.insert(0, PokerAgentType.QLEARNING)
+    N = 2048
+    env = PokerGPU(device=dev, agents=agents, n_players=6, max_players=10, n_games=N, seed=11)
+    out = train_agent_fused(env, agents, types, episodes=3, n_games=N, device=dev, max_episode_steps=30, reduce_stats=False,
+                            hand_metrics=HandMetrics(dev, N))
+    hm = out["hand_metrics"]
+    assert len(hm["episodes"]) == 3 and hm["final"]["total_hands"] == sum(e["hands_completed"] for e in hm["episodes"]) > 0
+    # chips are conserved per table, so what the learner's seat won over the finished hands is what the episodes report
+    assert abs(hm["final"]["total_bb_won"]) <= 100 * hm["final"]["total_hands"]
+    assert set(hm["final"]["slices"]) == {"seat", "player_count", "street_depth"}
