@@ -280,6 +280,16 @@ int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t 
                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter,
                           uint64_t table_id0, uint8_t* terminated, double* reward_sum, void* stream);
+/* The same in two halves, for data-parallel training (one process per GPU): pulse_qnet_train_grads runs launches 1-2
+ * and leaves the UNNORMALISED gradient sum in t->grad and {sum g^2, rows, sum td^2} in t->stats[0..2] without touching
+ * t->step; the caller all-reduces t->grad and t->stats[1..2] over the ranks (RCCL), stores the squared norm of the
+ * reduced gradient in t->stats[0], adds 1 to *t->step if the reduced row count is positive, and calls
+ * pulse_qnet_train_apply (launch 3) -- every rank then applies the identical update. */
+int pulse_qnet_train_grads(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
+                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
+                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter,
+                           uint64_t table_id0, uint8_t* terminated, double* reward_sum, void* stream);
+int pulse_qnet_train_apply(const PulseQNetTrain* t, void* stream);
 
 /* ---- Particle2D (environments/Particle2D/Particle2D.py:22-30) ---------------------------------- */
 int pulse_particle2d_step(float* state, const float* action, int32_t* steps, float* obs_out, float* rewards,

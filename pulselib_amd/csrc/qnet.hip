@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
         for (int off = 32; off >= 1; off >>= 1) { rows += __shfl_xor(rows, off); sq += __shfl_xor(sq, off); rew += __shfl_xor(rew, off); }
         if (threadIdx.x == 0) {
             a.scal[1] = rows; a.scal[2] = sq;
-            if (rows > 0.0f) *a.step += 1;
+            if (rows > 0.0f && a.step) *a.step += 1;
             if (a.reward_sum) *a.reward_sum += rew;
         }
     }
@@ -824,10 +824,11 @@ int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions) {
     return 128 * state_dim + 128 + 128 * 128 + 128 + 64 * 128 + 64 + 32 * 64 + 32 + 32 * n_actions + n_actions;
 }
 
-int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
-                          const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
-                          const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
-                          uint8_t* terminated, double* reward_sum, void* stream) {
+namespace {
+int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
+                   const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
+                   const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
+                   uint8_t* terminated, double* reward_sum, bool grads, bool apply, void* stream) {
     if (!t || !states || !actions || !rewards || !next_states || !dones)
         return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: null argument");
     const PulseQNet& n = t->net;
@@ -856,36 +857,62 @@ int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t 
     if (!(t->dropout_p >= 0.0f && t->dropout_p < 1.0f)) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: dropout_p outside [0, 1)");
     if (n_rows < 0) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: n_rows < 0");
     hipStream_t st = (hipStream_t)stream;
-    if (n_rows == 0) return 0;
-    TrainArgs a{};
-    a.net = t->net; a.tgt = t->target; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
-    a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
-    a.row_mask = row_mask; a.terminated = terminated; a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
-    a.gamma = t->gamma; a.drop_p = t->dropout_p;
-    const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
-        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
-        attr_set = true;
+    const unsigned eg = (unsigned)((np + 255) / 256);
+    if (grads && n_rows > 0) {
+        TrainArgs a{};
+        a.net = t->net; a.tgt = t->target; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
+        a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
+        a.row_mask = row_mask; a.terminated = terminated; a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
+        a.gamma = t->gamma; a.drop_p = t->dropout_p;
+        const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
+            if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
+            attr_set = true;
     }
     // persistent workgroups (4 wavefronts, 149 KB of LDS: one per CU) striding over the 256-row windows
     const int grid = std::min((n_rows + 255) / 256, (int)t->max_blocks);
     if (vec) hipLaunchKernelGGL((qnet_train_kernel<true>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
     else hipLaunchKernelGGL((qnet_train_kernel<false>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
     ReduceArgs r{};
-    r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.grad = t->grad; r.scal = t->stats; r.step = (long long*)t->step;
+    r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.grad = t->grad; r.scal = t->stats;
+    r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
     r.reward_sum = reward_sum;
-    const unsigned eg = (unsigned)((np + 255) / 256);
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(eg), dim3(256), 0, st, r);
-    AdamArgs b{};
-    b.params = t->params; b.target = t->target_params; b.grad = t->grad; b.m = t->exp_avg; b.v = t->exp_avg_sq; b.step = (const long long*)t->step;
-    b.scal = t->stats; b.report = t->report; b.n_params = np; b.lr = t->lr; b.wd = t->weight_decay; b.beta1 = t->beta1; b.beta2 = t->beta2;
-    b.eps = t->eps; b.max_norm = t->max_grad_norm; b.update_freq = t->update_freq;
-    hipLaunchKernelGGL(qnet_adamw_kernel, dim3(eg), dim3(256), 0, st, b);
+    }
+    if (apply && (n_rows > 0 || !grads)) {
+        AdamArgs b{};
+        b.params = t->params; b.target = t->target_params; b.grad = t->grad; b.m = t->exp_avg; b.v = t->exp_avg_sq; b.step = (const long long*)t->step;
+        b.scal = t->stats; b.report = t->report; b.n_params = np; b.lr = t->lr; b.wd = t->weight_decay; b.beta1 = t->beta1; b.beta2 = t->beta2;
+        b.eps = t->eps; b.max_norm = t->max_grad_norm; b.update_freq = t->update_freq;
+        hipLaunchKernelGGL(qnet_adamw_kernel, dim3(eg), dim3(256), 0, st, b);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : pulse::fail_hip((int)e, "pulse_qnet_train_step launch");
+}
+}  // namespace
+
+int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
+                          const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
+                          const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
+                          uint8_t* terminated, double* reward_sum, void* stream) {
+    return train_launches(t, states, row_stride, actions, rewards, next_states, next_stride, dones, row_mask, n_rows, seed, step_counter,
+                          table_id0, terminated, reward_sum, true, true, stream);
+}
+
+int pulse_qnet_train_grads(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
+                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
+                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
+                           uint8_t* terminated, double* reward_sum, void* stream) {
+    return train_launches(t, states, row_stride, actions, rewards, next_states, next_stride, dones, row_mask, n_rows, seed, step_counter,
+                          table_id0, terminated, reward_sum, true, false, stream);
+}
+
+int pulse_qnet_train_apply(const PulseQNetTrain* t, void* stream) {
+    static const float dummy_f = 0.0f; static const int64_t dummy_a = 0; static const uint8_t dummy_d = 0;
+    return train_launches(t, &dummy_f, 64, &dummy_a, &dummy_f, &dummy_f, 64, &dummy_d, nullptr, 0, 0, 0, 0, nullptr, nullptr, false, true, stream);
 }
 
 }  // extern "C"

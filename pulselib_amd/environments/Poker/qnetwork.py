@@ -72,6 +72,7 @@ class PokerQNetwork(nn.Module):
         self.seed, self.table_id0 = int(seed), int(table_id0)
         self._calls = 0
         self._lr_gate = None
+        self.data_parallel = True            # under torch.distributed with > 1 rank: all-reduce the gradient every step
 
     # ------------------------------------------------------------------ torch side
     def forward(self, states):
@@ -227,11 +228,28 @@ class PokerQNetwork(nn.Module):
             rewards = rewards.to(torch.float32).contiguous()
         self._calls += 1
         step = (1 << 41) + self._calls if step_counter is None else int(step_counter)
-        _native.check(_native.lib().pulse_qnet_train_step(
-            C.byref(t), states.data_ptr(), states.stride(0), actions.data_ptr(), rewards.data_ptr(), next_states.data_ptr(),
-            next_states.stride(0), dones8.data_ptr(), None if mask8 is None else mask8.data_ptr(), n, self.seed & (2**64 - 1), step,
-            self.table_id0, term8, None if reward_sum is None else reward_sum.data_ptr(),
-            _native.current_stream(states.device)), "pulse_qnet_train_step")
+        lib, stream = _native.lib(), _native.current_stream(states.device)
+        args = (C.byref(t), states.data_ptr(), states.stride(0), actions.data_ptr(), rewards.data_ptr(), next_states.data_ptr(),
+                next_states.stride(0), dones8.data_ptr(), None if mask8 is None else mask8.data_ptr(), n, self.seed & (2**64 - 1), step,
+                self.table_id0, term8, None if reward_sum is None else reward_sum.data_ptr(), stream)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self.data_parallel:
+            # data-parallel learner: every rank trains on its own tables, the 130 KB gradient sum and the
+            # row count are all-reduced over xGMI, every rank applies the identical AdamW step
+            _native.check(lib.pulse_qnet_train_grads(*args), "pulse_qnet_train_grads")
+            nat = self._native
+            grad, stats = nat["grad"], nat["stats"]
+            if dist.get_backend() == "gloo":          # one-GPU rehearsal / CPU-side reduction
+                g, s2 = grad.cpu(), stats[1:3].cpu()
+                dist.all_reduce(g); dist.all_reduce(s2)
+                grad.copy_(g); stats[1:3].copy_(s2)
+            else:
+                dist.all_reduce(grad); dist.all_reduce(stats[1:3])
+            stats[0:1].copy_(grad.square().sum().reshape(1))
+            nat["step"] += (stats[1:2] > 0).to(torch.int64)
+            _native.check(lib.pulse_qnet_train_apply(C.byref(t), stream), "pulse_qnet_train_apply")
+        else:
+            _native.check(lib.pulse_qnet_train_step(*args), "pulse_qnet_train_step")
         self.step_count += 1             # calls; the optimizer-step count (calls with at least one valid row) is native_steps()
         return self._native["report"]
 

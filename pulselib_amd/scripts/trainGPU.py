@@ -100,7 +100,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
       PyTorch autograd) -> every 5th step the lagged done-count.
     `active_players` is drawn from a host RNG (the reference reads a device randint back, PokerGPU.py:76-77) and the
     stop rule is decided on the newest count that already reached the host (stoprule.py); `stop_rule="sync"`
-    restores the reference's blocking check.  Needs a learner with `act_into` / `train_step_masked` (qnetwork.py).
+    restores the reference's blocking check, `"steps"` runs every episode to `max_episode_steps` (data-parallel runs:
+    the ranks' collectives must stay in step, and a rank-local stop decision would not).  Needs a learner with `act_into` / `train_step_masked` (qnetwork.py).
     `hand_metrics` (utils.performance.HandMetrics) adds the BB/100 side-channel of trainGPU_performance.py:192-206 as
     one more launch per step; its per-episode summaries come back under "hand_metrics"."""
     import random
@@ -162,7 +163,7 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
                 step_hook(episode, idx, state_before, actions, rewards, next_state, dones, active_games)
             state = next_state
             global_step += 1
-            if idx % CHECK_INTERVAL == 0:                                             # :27-33 cadence
+            if idx % CHECK_INTERVAL == 0 and stop_rule != "steps":                    # :27-33 cadence
                 done_count.submit(terminated)
                 if done_count.over(blocking=stop_rule == "sync"):
                     break

@@ -62,14 +62,14 @@ def test_hip_forward_row_counts_and_large_batch(n):
     np.testing.assert_allclose(got, orc.qnet_forward(w, b, states.numpy()), rtol=0, atol=Q_TOL)
 
 
-@pytest.mark.parametrize("eps", [0.0, 0.3, 1.0])
-def test_hip_act_matches_oracle_and_leaves_other_seats_alone(g, eps):
+@pytest.mark.parametrize("eps,case", [(0.0, "s40"), (0.3, "s40"), (1.0, "s40"), (0.3, "s27")])
+def test_hip_act_matches_oracle_and_leaves_other_seats_alone(g, eps, case):
     from oracle import oracle as orc
     from pulselib_amd import _native
-    q = _qnet(g, "s40", seed=4242, table_id0=10_000_000_000)
-    n = 5000
+    q = _qnet(g, case, seed=4242, table_id0=10_000_000_000)
+    n, sd = 5000, q.state_dim
     rng = np.random.default_rng(5)
-    states = torch.from_numpy((rng.standard_normal((n, 40)) * 3).astype(np.float32)).to(DEV)
+    states = torch.from_numpy((rng.standard_normal((n, sd)) * 3).astype(np.float32)).to(DEV)
     seat = torch.from_numpy(rng.integers(0, 10, n).astype(np.int32)).to(DEV)
     seat[64:192] = 3            # a full and an empty wavefront window
     seat[192:256] = 4
@@ -78,7 +78,7 @@ def test_hip_act_matches_oracle_and_leaves_other_seats_alone(g, eps):
     term = torch.from_numpy(rng.random(n) < 0.25).to(DEV)
     mask = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
     net = q._net_struct(q.network)
-    _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), 40, n, seat.data_ptr(), 3, eps, 4242, 77,
+    _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), sd, n, seat.data_ptr(), 3, eps, 4242, 77,
                                                10_000_000_000, actions.data_ptr(), qrows.data_ptr(), term.data_ptr(), mask.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), "pulse_qnet_act")
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), (seat.cpu().numpy() == 3) & ~term.cpu().numpy().astype(bool))
@@ -219,12 +219,14 @@ def _batch(n, seed, state_dim=40):
                 rewards=(rng.standard_normal(n) * 3).astype(np.float32), dones=rng.random(n) < 0.3, row_mask=rng.random(n) < 0.6)
 
 
-@pytest.mark.parametrize("n,drop", [(1000, True), (1000, False), (37, True), (70000, True)])
-def test_native_train_step_matches_oracle(g, n, drop):
+@pytest.mark.parametrize("n,drop,case", [(1000, True, "s40"), (1000, False, "s40"), (37, True, "s40"), (70000, True, "s40"),
+                                         (1500, True, "s27")])
+def test_native_train_step_matches_oracle(g, n, drop, case):
     """Three native updates against the oracle's scalar restatement (same dropout draws, same AdamW arithmetic):
     row count, loss, gradient norm and the parameters after every step; target sync at update_freq."""
     from oracle import oracle as orc
-    q = _qnet(g, "s40", seed=77, table_id0=5_000_000_000)
+    q = _qnet(g, case, seed=77, table_id0=5_000_000_000)        # s27: the scalar-load (unaligned state_dim) variants of the kernels
+    sd = q.state_dim
     q.update_freq = 2
     if not drop:
         q.network.eval()
@@ -232,7 +234,7 @@ def test_native_train_step_matches_oracle(g, n, drop):
     m = np.zeros_like(p); v = np.zeros_like(p)
     t_opt = 0
     for it in range(3):
-        b = _batch(n, 100 * n + it)
+        b = _batch(n, 100 * n + it, sd)
         if it == 2:
             b["row_mask"][:] = False                       # nothing valid: the step must be a no-op
         dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}

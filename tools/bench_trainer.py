@@ -32,16 +32,28 @@ def main():
     from pulselib_amd.environments.Poker import PokerGPU, PokerQNetwork, load_gpu_agents
     from pulselib_amd.environments.Poker.utils import PokerAgentType
     from pulselib_amd.scripts.trainGPU import train_agent, train_agent_fused
-    device = torch.device("cuda", 0)
+    # one process per GPU under torchrun (tables sharded, the learner data-parallel: gradient all-reduce over RCCL);
+    # PULSE_BENCH_ONE_DEVICE=1 rehearses that on one GPU with gloo
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = os.environ.get("PULSE_BENCH_ONE_DEVICE") == "1"
+    device = torch.device("cuda", 0 if one_device else local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo") if one_device else dist.init_process_group(backend="nccl", device_id=device)
     agents, types = load_gpu_agents(device, 9, AGENTS, 100, 13)
+    torch.manual_seed(20260401)                   # identical initial weights on every rank
     q = PokerQNetwork(None, device, gamma=.95, update_freq=20, state_dim=40, action_dim=13, learning_rate=2e-4, weight_decay=1e-5,
-                      seed=20260401)
+                      seed=20260401, table_id0=rank * args.tables)
     agents.insert(0, q)
     types.insert(0, PokerAgentType.QLEARNING)
     env = PokerGPU(device=device, agents=agents, n_players=10, max_players=10, n_games=args.tables, starting_bbs=100, max_bbs=1000,
-                   w1=.5, w2=.3, K=100, alpha=50, seed=20260401)
+                   w1=.5, w2=.3, K=100, alpha=50, seed=20260401, table_id0=rank * args.tables)
     run = train_agent_fused if args.loop == "fused" else train_agent
-    kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=False)
+    kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=world > 1)
+    if world > 1:
+        kw["stop_rule"] = "steps"                 # every rank must take the same number of steps per episode (collectives inside)
     if args.loop == "fused":
         kw["learner"] = args.learner
     run(env, agents, types, args.warmup, args.tables, device, **kw)
@@ -51,11 +63,21 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     steps = out["total_steps"] // args.tables
-    print(json.dumps({"metric": "trainer-loop env-steps/sec, Poker batched tables (learner acting and learning every step)",
-                      "value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "n_gpus": 1, "loop": args.loop, "learner": args.learner if args.loop == "fused" else "torch",
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        out["total_steps"] *= world
+    if rank == 0:
+        print(json.dumps({"metric": "trainer-loop env-steps/sec, Poker batched tables (learner acting and learning every step)",
+                      "value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "n_gpus": world, "loop": args.loop, "learner": args.learner if args.loop == "fused" else "torch",
                       "tables": args.tables, "episodes": args.episodes, "step_calls_counted": steps,
                       "ms_per_step": elapsed / max(steps, 1) * 1e3, "learner_calls": q.step_count,
                       "mean_episode_reward": sum(out["episode_rewards"]) / max(len(out["episode_rewards"]), 1)}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
