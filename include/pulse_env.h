@@ -155,12 +155,26 @@ int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types,
 /* Roll-out: n_steps fused policy+step launches enqueued back to back from native code (no host work
  * between launches).  v_even/v_odd are the two ping-pong views (is_done <-> is_done_out swapped);
  * step i uses v_even / rewards_even when i is even.  Philox offset of step i = step_counter0 + i.
- * time_every > 0: the chunk of n_steps launches is bracketed by ONE HIP event pair on `stream`; read the
- * summed time and the number of launches it covers with pulse_rollout_timing_collect() AFTER
+ * time_every > 0: every time_every-th call brackets its chunk of n_steps launches with ONE HIP event pair on
+ * `stream`; read the summed time and the number of launches it covers with pulse_rollout_timing_collect() AFTER
  * synchronising the stream (mean per launch = sum / launches, kernel boundaries included). */
 int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
-                        float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stream);
+                        float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stoprule,
+                        void* stream);
+/* `stoprule` (NULL or a pulse_stoprule_create handle): pulse_stoprule_submit on the done flags of the last state.
+ *
+ * The trainer's episode stop rule (scripts/Poker/trainGPU.py:27-33: every 5th step, > threshold of the tables done)
+ * without its blocking read: submit counts the done flags in stream order and copies the count to pinned host memory
+ * on a side stream; over() answers from the counts that have ALREADY arrived (blocking != 0: waits for all submitted
+ * ones -- the reference's behaviour); drain() consumes what is in flight (episode boundary).  This handle is the one
+ * piece of state the library keeps: a side stream, four events, 16 bytes of device and of pinned host memory,
+ * created on the current device. */
+int pulse_stoprule_create(int32_t n_tables, double threshold, void** handle);
+int pulse_stoprule_submit(void* handle, const uint8_t* is_done, void* stream);
+int pulse_stoprule_over(void* handle, int32_t blocking, int32_t* over);
+int pulse_stoprule_drain(void* handle);
+int pulse_stoprule_destroy(void* handle);
 int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed);
 
 /* Diagnostic only (tools/ablate_step.py): fused policy+step with phases compiled out, to price them. */

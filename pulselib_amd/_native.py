@@ -87,7 +87,12 @@ SYMBOLS = {
     "pulse_poker_reset": (C.c_int, [_P, _P, _P]),
     "pulse_poker_policy": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _U64, _U64, _U64, _P, _P]),
     "pulse_poker_policy_step": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, _P]),
-    "pulse_poker_rollout": (C.c_int, [_P, _P, _P, _U64, _U64, _U64, _P, _P, _P, _I32, _I32, _P]),
+    "pulse_poker_rollout": (C.c_int, [_P, _P, _P, _U64, _U64, _U64, _P, _P, _P, _I32, _I32, _P, _P]),
+    "pulse_stoprule_create": (C.c_int, [_I32, C.c_double, _P]),
+    "pulse_stoprule_submit": (C.c_int, [_P, _P, _P]),
+    "pulse_stoprule_over": (C.c_int, [_P, _I32, _P]),
+    "pulse_stoprule_drain": (C.c_int, [_P]),
+    "pulse_stoprule_destroy": (C.c_int, [_P]),
     "pulse_rollout_timing_collect": (C.c_int, [_P, _P]),
     "pulse_poker_ablate": (C.c_int, [_P, _U32, _P, _P, _U64, _U64, _P]),
     "pulse_calib_stream": (C.c_int, [_P, _U64, _I32, _P]),

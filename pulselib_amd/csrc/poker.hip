@@ -1132,11 +1132,114 @@ constexpr int kMaxTimed = 4096;
 hipEvent_t g_ev_start[kMaxTimed], g_ev_stop[kMaxTimed];
 int g_ev_created = 0, g_ev_used = 0;
 int g_ev_launches[kMaxTimed];
+long long g_rollout_calls = 0;
+}
+
+// ---- stop rule without a host sync (scripts/Poker/trainGPU.py:27-33), native side -------------------------
+// After a chunk of steps: count the finished tables on the device (cumulative counter: no memset in the loop), copy
+// the count to pinned host memory on a side stream, decide on the newest count that has ALREADY arrived.  Done
+// here rather than in Python because the chunk boundary -- a kernel launch, two event records, a stream wait and
+// an async copy -- cost more host time through torch (~50 us) than the five step launches of the chunk take on
+// the GPU, which left the GPU idle a quarter of the time.
+struct PulseStopRule {
+    hipStream_t side;
+    hipEvent_t ready[2], copied[2];
+    unsigned long long* counts_dev;        // [2] cumulative per slot
+    unsigned long long* counts_host;       // [2] pinned
+    unsigned long long seen[2];
+    long long pending[2]; int n_pending;
+    long long chunk;
+    int n; double threshold; bool late_over;
+};
+
+namespace {
+bool stoprule_pop(PulseStopRule* h) {
+    const long long c = h->pending[0];
+    h->pending[0] = h->pending[1]; --h->n_pending;
+    const unsigned long long total = h->counts_host[c & 1];
+    const unsigned long long n_done = total - h->seen[c & 1];
+    h->seen[c & 1] = total;
+    return (double)n_done > h->threshold * (double)h->n;
+}
+}  // namespace
+
+int pulse_stoprule_create(int32_t n_tables, double threshold, void** out) {
+    if (!out || n_tables < 0) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_create: bad argument");
+    PulseStopRule* h = new PulseStopRule();
+    h->n = n_tables; h->threshold = threshold;
+    hipError_t e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&h->ready[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->copied[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counts_dev), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->counts_dev, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->counts_host), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) { delete h; return pulse::fail_hip((int)e, "pulse_stoprule_create"); }
+    h->counts_host[0] = h->counts_host[1] = 0;
+    *out = h;
+    return 0;
+}
+
+int pulse_stoprule_destroy(void* handle) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h) return 0;
+    (void)hipStreamSynchronize(h->side);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ready[i]); (void)hipEventDestroy(h->copied[i]); }
+    (void)hipFree(h->counts_dev); (void)hipHostFree(h->counts_host); (void)hipStreamDestroy(h->side);
+    delete h;
+    return 0;
+}
+
+int pulse_stoprule_submit(void* handle, const uint8_t* is_done, void* stream) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h || !is_done) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_submit: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    while (h->n_pending >= 2) {                            // bounded run-ahead: never reuse a slot still in flight
+        (void)hipEventSynchronize(h->copied[h->pending[0] & 1]);
+        h->late_over = stoprule_pop(h) || h->late_over;
+    }
+    const int slot = (int)(h->chunk & 1);
+    if (h->n > 0) {
+        const int grid = min(1024, (h->n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(poker_stats_kernel, dim3(grid), dim3(kBlock), 0, st, is_done, (const float*)nullptr, (const uint8_t*)nullptr, h->n,
+                           h->counts_dev + slot, (double*)nullptr);
+    }
+    hipError_t e = hipEventRecord(h->ready[slot], st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ready[slot], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->counts_host + slot, h->counts_dev + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->side);
+    if (e == hipSuccess) e = hipEventRecord(h->copied[slot], h->side);
+    if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_stoprule_submit");
+    h->pending[h->n_pending++] = h->chunk;
+    ++h->chunk;
+    return 0;
+}
+
+int pulse_stoprule_over(void* handle, int32_t blocking, int32_t* over) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h || !over) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_over: null argument");
+    bool o = h->late_over; h->late_over = false;
+    while (h->n_pending > 0) {
+        hipEvent_t ev = h->copied[h->pending[0] & 1];
+        if (blocking) (void)hipEventSynchronize(ev);
+        else if (hipEventQuery(ev) != hipSuccess) break;
+        o = stoprule_pop(h) || o;
+    }
+    *over = o ? 1 : 0;
+    return 0;
+}
+
+int pulse_stoprule_drain(void* handle) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_drain: null argument");
+    while (h->n_pending > 0) { (void)hipEventSynchronize(h->copied[h->pending[0] & 1]); (void)stoprule_pop(h); }
+    h->late_over = false;
+    return 0;
 }
 
 int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions, float* rewards_even,
-                        float* rewards_odd, int32_t n_steps, int32_t time_every, void* stream) {
+                        float* rewards_odd, int32_t n_steps, int32_t time_every, void* stoprule, void* stream) {
     if (int rc = check_view(v_even, "pulse_poker_rollout")) return rc;
     if (int rc = check_view(v_odd, "pulse_poker_rollout")) return rc;
     if (!actions || !rewards_even || !rewards_odd || !agent_types || n_steps < 0)
@@ -1145,7 +1248,8 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     hipStream_t st = (hipStream_t)stream;
     const uint64_t packed = pack_types(agent_types, v_even->n_players);
     // time_every > 0: bracket the whole chunk of launches with one HIP event pair on the launch stream
-    const bool timed = time_every > 0 && n_steps > 0 && g_ev_used < kMaxTimed;
+    // (every time_every-th call only: the two timing events cost about as much queue time as a tenth of a chunk)
+    const bool timed = time_every > 0 && n_steps > 0 && g_ev_used < kMaxTimed && (g_rollout_calls++ % time_every) == 0;
     if (timed) {
         if (g_ev_used >= g_ev_created) {
             if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess || hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess)
@@ -1161,6 +1265,10 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
         launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
     }
     if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); g_ev_launches[g_ev_used] = n_steps; ++g_ev_used; }
+    if (stoprule && n_steps > 0) {                         // the done flags of the state the last launch produced
+        const PulsePokerView& last = ((n_steps - 1) & 1) ? *v_odd : *v_even;
+        if (int rc = pulse_stoprule_submit(stoprule, last.is_done_out, stream)) return rc;
+    }
     return finish_launch("pulse_poker_rollout");
 }
 

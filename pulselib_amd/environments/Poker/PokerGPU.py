@@ -329,10 +329,11 @@ class PokerGPU(_EnvBase):
         object.__setattr__(self, "is_done", self._done_bufs[pp])
         return self.obs, rewards, self.is_done, self.is_truncated, self.get_info()
 
-    def rollout(self, agent_types, actions, n_steps, step_counter0, time_every=0):
+    def rollout(self, agent_types, actions, n_steps, step_counter0, time_every=0, stop_rule=None):
         """`n_steps` fused policy+step launches enqueued back to back by the native library (no Python
         between launches).  Equivalent to calling policy_step(agent_types, actions, step_counter0 + i)
-        for i in range(n_steps); returns what the last step returned."""
+        for i in range(n_steps); returns what the last step returned.  `stop_rule` (stoprule.LaggedDoneCount):
+        its done-count of the final state is submitted by the same native call."""
         actions = self._actions(actions)
         key = tuple(int(x) for x in agent_types)
         types = self._types_cache.get(key)
@@ -347,6 +348,7 @@ class PokerGPU(_EnvBase):
                                                     self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
                                                     actions.data_ptr(), self._rewards[pp].data_ptr(),
                                                     self._rewards[1 - pp].data_ptr(), int(n_steps), int(time_every),
+                                                    None if stop_rule is None else stop_rule.handle,
                                                     self._stream()), "pulse_poker_rollout")
         if n_steps <= 0:
             return self.obs, self._rewards[pp], self.is_done, self.is_truncated, self.get_info()

@@ -2,11 +2,14 @@
 
 scripts/Poker/trainGPU.py:27-33 ends an episode when, at every 5th step, `terminated.float().mean() > 0.8` -- a
 blocking device->host read in the middle of the loop.  `LaggedDoneCount` keeps the rule and drops the wait: after a
-chunk of steps the number of finished tables is counted on the device (pulse_poker_stats adds into a cumulative
-counter: no memset in the loop), copied to pinned host memory on a side stream, and the decision is taken on the
-newest count that has ALREADY arrived -- normally the one of the previous chunk.  `blocking=True` waits for the
-current chunk's count instead (the reference's behaviour)."""
+chunk of steps the number of finished tables is counted on the device (cumulative counter: no memset in the loop),
+copied to pinned host memory on a side stream, and the decision is taken on the newest count that has ALREADY
+arrived -- normally the one of the previous chunk.  `blocking=True` waits for the current chunk's count instead (the
+reference's behaviour).  The mechanics live in the native library (pulse_stoprule_*, csrc/poker.hip): done through
+torch, the chunk boundary cost more host time than the chunk's five step launches take on the GPU."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
@@ -16,55 +19,35 @@ from . import _native
 class LaggedDoneCount:
     def __init__(self, device, n_tables: int, threshold: float = 0.8):
         self.device, self.n, self.threshold = device, int(n_tables), float(threshold)
-        self.side = torch.cuda.Stream(device=device)
-        self.counts_dev = torch.zeros(2, dtype=torch.int64, device=device)
-        self.counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()
-        self.copy_events = [torch.cuda.Event(), torch.cuda.Event()]
-        self.seen = [0, 0]             # cumulative counts already consumed per slot
-        self.pending = []              # chunk ids whose count is in flight
-        self.chunk = 0
-        self._late_over = False
         self._lib = _native.lib()
-
-    def _pop(self) -> bool:
-        c = self.pending.pop(0)
-        total = int(self.counts_host[c & 1].item())
-        n_done = total - self.seen[c & 1]
-        self.seen[c & 1] = total
-        return n_done > self.threshold * self.n
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _native.check(self._lib.pulse_stoprule_create(self.n, self.threshold, C.byref(h)), "pulse_stoprule_create")
+        self.handle = h
 
     def submit(self, is_done: torch.Tensor) -> None:
-        """Count the set flags of `is_done` (bool/uint8[n]) in stream order and start the copy to the host."""
-        slot = self.chunk & 1
-        while len(self.pending) >= 2:                      # bounded run-ahead: never reuse a slot still in flight
-            self.copy_events[self.pending[0] & 1].synchronize()
-            self._late_over = self._pop() or self._late_over
-        _native.check(self._lib.pulse_poker_stats(is_done.data_ptr(), None, None, self.n, self.counts_dev[slot:].data_ptr(), None,
-                                                  torch.cuda.current_stream(self.device).cuda_stream), "pulse_poker_stats")
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            self.counts_host[slot:slot + 1].copy_(self.counts_dev[slot:slot + 1], non_blocking=True)
-            self.copy_events[slot].record(self.side)
-        self.pending.append(self.chunk)
-        self.chunk += 1
+        """Count the set flags of `is_done` (bool/uint8[n]) in stream order and start the copy to the host.
+        (PokerGPU.rollout(..., stop_rule=self) does this inside the same native call as the step launches.)"""
+        _native.check(self._lib.pulse_stoprule_submit(self.handle, is_done.data_ptr(),
+                                                      torch.cuda.current_stream(self.device).cuda_stream), "pulse_stoprule_submit")
 
     def over(self, blocking: bool = False) -> bool:
         """True if any count that has reached the host since the last call exceeds the threshold."""
-        over, self._late_over = self._late_over, False
-        while self.pending:
-            ev = self.copy_events[self.pending[0] & 1]
-            if blocking:
-                ev.synchronize()
-            elif not ev.query():
-                break
-            over = self._pop() or over
-        return over
+        flag = C.c_int32(0)
+        _native.check(self._lib.pulse_stoprule_over(self.handle, 1 if blocking else 0, C.byref(flag)), "pulse_stoprule_over")
+        return bool(flag.value)
 
     def drain(self) -> None:
         """Episode boundary: consume what is in flight so the cumulative counters stay consistent."""
-        while self.pending:
-            self.copy_events[self.pending[0] & 1].synchronize()
-            self._pop()
-        self._late_over = False
+        _native.check(self._lib.pulse_stoprule_drain(self.handle), "pulse_stoprule_drain")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.pulse_stoprule_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

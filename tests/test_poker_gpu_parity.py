@@ -518,3 +518,48 @@ def test_hip_matches_oracle_at_config4_shard_size(oracle_table):
     # unless a folded player out-invested every contender, which the oracle reproduces identically)
     total = to_np(env.stacks).sum(dtype=np.int64) + to_np(env.pots).sum(dtype=np.int64)
     assert total == ref.stacks.sum(dtype=np.int64) + ref.pots.sum(dtype=np.int64)
+
+
+def test_native_stop_rule_counts_lags_and_drains():
+    """pulselib_amd.stoprule.LaggedDoneCount (pulse_stoprule_*): the rule of trainGPU.py:27-33 -- more than 80 % of the
+    tables done -- on counts copied back asynchronously; cumulative device counters, two submissions in flight at most."""
+    from pulselib_amd.stoprule import LaggedDoneCount
+    dev = torch.device(DEV)
+    n = 10000
+    rule = LaggedDoneCount(dev, n, 0.8)
+    flags = torch.zeros(n, dtype=torch.bool, device=dev)
+    rule.submit(flags)
+    assert rule.over(blocking=True) is False
+    flags[:8000] = True                              # exactly 80 %: not over ("> 0.8")
+    rule.submit(flags)
+    assert rule.over(blocking=True) is False
+    flags[8000] = True
+    rule.submit(flags)
+    assert rule.over(blocking=True) is True
+    assert rule.over(blocking=True) is False         # a decision is reported once
+    # run-ahead: several submissions without polling keep the newest verdicts, none is lost
+    flags.zero_()
+    for k in range(5):
+        if k == 2:
+            flags[:9000] = True
+        if k == 3:
+            flags.zero_()
+        rule.submit(flags)
+    assert rule.over(blocking=True) is True          # submission 2 was over the threshold
+    rule.submit(flags)
+    rule.drain()
+    assert rule.over(blocking=False) is False
+    # inside the native rollout call: the done flags of the state the last launch produced
+    env = _gpu_env(n_players=6, max_players=10, n_games=4096, seed=3)
+    env.reset(options={"active_players": 6})
+    r2 = LaggedDoneCount(dev, 4096, 0.8)
+    actions = torch.zeros(4096, dtype=torch.long, device=dev)
+    types = [1, 1, 1, 1, 1, 1]                       # every seat plays `random`: hands end within a few dozen steps
+    over_at = None
+    for chunk in range(40):
+        env.rollout(types, actions, 5, 5 * chunk, stop_rule=r2)
+        if r2.over(blocking=True):
+            over_at = chunk
+            break
+    assert over_at is not None and env.is_done.float().mean().item() > 0.8
+    rule.close(); r2.close()
