@@ -89,7 +89,8 @@ class Runner:
         self.steps_in_episode = 0
         from pulselib_amd.stoprule import LaggedDoneCount
         self.done_count = LaggedDoneCount(device, self.N, TERMINATION_THRESHOLD)
-        self.episode_stats = torch.zeros(2, dtype=torch.float64, device=device)
+        self.episode_stats = torch.zeros(2, dtype=torch.float64, device=device)          # all-reduced copy (cumulative over episodes)
+        self.episode_stats_local = torch.zeros(2, dtype=torch.float64, device=device)
         self.new_episode()
 
     def new_episode(self):
@@ -128,12 +129,15 @@ class Runner:
             if getattr(self, "_stats_work", None) is not None:
                 self._stats_work.wait()              # stream-ordered for RCCL: the buffer is about to be rewritten
                 self._stats_work = None
-            self.episode_stats[0] = self.env.is_done.sum()
-            self.episode_stats[1] = self.env._rewards[0].sum()
+            # one launch: {sum of the last step's rewards, tables done} added into a cumulative double[2]
+            env = self.env
+            env._lib.pulse_poker_stats(env.is_done.data_ptr(), env._rewards[0].data_ptr(), None, self.N, None,
+                                       self.episode_stats_local.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
             if dist.get_backend() == "gloo":      # one-GPU rehearsal: gloo reduces host copies
-                host = self.episode_stats.cpu()
+                host = self.episode_stats_local.cpu()
                 dist.all_reduce(host)
             else:
+                self.episode_stats.copy_(self.episode_stats_local)
                 self._stats_work = dist.all_reduce(self.episode_stats, async_op=True)
         self.new_episode()
 

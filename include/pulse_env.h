@@ -186,7 +186,8 @@ int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* action
 int pulse_calib_stream(int32_t* buf, uint64_t n_words, int32_t write, void* stream);
 
 /* Episode statistics for the trainer's stop rule and returns (scripts/Poker/trainGPU.py:27-33,96):
- * stats device int64[2] += {#tables with is_done, 0}; fstats device double[1] += sum(rewards[mask]). */
+ * stats device int64[2] += {#tables with is_done, 0}; fstats device double[1] += sum(rewards[mask]).
+ * stats NULL: the done count goes to fstats[1] instead (double[2] = {reward sum, done count}: one tensor to all-reduce). */
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n,
                       int64_t* stats, double* fstats, void* stream);
 

@@ -883,7 +883,7 @@ __global__ __launch_bounds__(kBlock) void poker_stats_kernel(const uint8_t* __re
     if (threadIdx.x == 0) {
         int c = 0; double sm = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) { c += scnt[w]; sm += ssum[w]; }
-        if (c) atomicAdd(stats, (unsigned long long)c);
+        if (c) { if (stats) atomicAdd(stats, (unsigned long long)c); else atomicAdd(fstats + 1, (double)c); }
         if (rewards && sm != 0.0) atomicAdd(fstats, sm);
     }
 }
@@ -1290,7 +1290,7 @@ int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed) {
 
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n, int64_t* stats,
                       double* fstats, void* stream) {
-    if (!stats || (rewards && !fstats) || n < 0) return pulse::fail(PULSE_EINVAL, "pulse_poker_stats: bad argument");
+    if ((!stats && !fstats) || (rewards && !fstats) || n < 0) return pulse::fail(PULSE_EINVAL, "pulse_poker_stats: bad argument");
     if (n == 0) return 0;
     const int grid = min(1024, (n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(poker_stats_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, is_done, rewards, mask, n,

@@ -563,3 +563,25 @@ def test_native_stop_rule_counts_lags_and_drains():
             break
     assert over_at is not None and env.is_done.float().mean().item() > 0.8
     rule.close(); r2.close()
+
+
+def test_stats_kernel_forms():
+    """pulse_poker_stats: done count into int64 / reward sum under a mask / both into one double[2] (the tensor a rank all-reduces)."""
+    from pulselib_amd import _native
+    lib = _native.lib()
+    rng = np.random.default_rng(8)
+    n = 70001
+    done = rng.random(n) < 0.37
+    mask = rng.random(n) < 0.5
+    rew = rng.standard_normal(n).astype(np.float32)
+    d, m, r = (torch.from_numpy(x).to(DEV) for x in (done, mask, rew))
+    st = torch.cuda.current_stream().cuda_stream
+    cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+    fs = torch.zeros(1, dtype=torch.float64, device=DEV)
+    _native.check(lib.pulse_poker_stats(d.data_ptr(), r.data_ptr(), m.data_ptr(), n, cnt.data_ptr(), fs.data_ptr(), st), "stats")
+    _native.check(lib.pulse_poker_stats(d.data_ptr(), None, None, n, cnt.data_ptr(), None, st), "stats")      # cumulative
+    assert int(cnt[0]) == 2 * int(done.sum())
+    assert abs(float(fs[0]) - float(rew[mask].astype(np.float64).sum())) < 1e-6
+    both = torch.zeros(2, dtype=torch.float64, device=DEV)
+    _native.check(lib.pulse_poker_stats(d.data_ptr(), r.data_ptr(), None, n, None, both.data_ptr(), st), "stats")
+    assert float(both[1]) == float(done.sum()) and abs(float(both[0]) - float(rew.astype(np.float64).sum())) < 1e-6
