@@ -15,7 +15,8 @@ finished tables included (trainGPU.py:108).  Resets run inside the timed region 
 
 Prints ONE JSON line (rank 0).  `roofline` prices the fused step kernel: algorithmic bytes per launch
 (453 B per table-step) over the kernel's mean duration from HIP event pairs recorded
-on the launch stream around every 5-launch chunk of the timed region (kernel boundaries included).  `cpu_baseline` times the oracle
+on the launch stream around every 8th 5-launch chunk of the timed region (kernel boundaries included; bracketing every
+chunk cost 10 % of the throughput it was measuring).  `cpu_baseline` times the oracle
 (oracle/poker_oracle.c, the CPU restatement of the same policy+step) on the host cores, rank 0 at N=1 only.
 """
 from __future__ import annotations
