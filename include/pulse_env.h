@@ -162,7 +162,9 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
                         float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stoprule,
                         void* stream);
-/* `stoprule` (NULL or a pulse_stoprule_create handle): pulse_stoprule_submit on the done flags of the last state.
+/* `stoprule` (NULL or a pulse_stoprule_create handle): the done tables of the last state are counted for it -- by the
+ * last launch itself (each wavefront stores its count; no extra kernel), equivalent to pulse_stoprule_submit on the
+ * final done flags.
  *
  * The trainer's episode stop rule (scripts/Poker/trainGPU.py:27-33: every 5th step, > threshold of the tables done)
  * without its blocking read: submit counts the done flags in stream order and copies the count to pinned host memory

@@ -161,7 +161,10 @@ template <class T> __device__ __forceinline__ void sto(T* __restrict__ base, uin
 }
 
 // ---------------------------------------------------------------- the fused step
-struct PolicyArgs { uint64_t types_packed, seed, step_counter, table_id0; };
+struct PolicyArgs {
+    uint64_t types_packed, seed, step_counter, table_id0;
+    uint32_t* wave_done;                   // nullptr, or one word per wavefront of the launch: tables done after this step
+};
 // In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
 // in the product): lane 0 of every wavefront stores s_memtime at phase boundaries into a buffer of its own.
 #ifndef PULSE_STAMPS
@@ -672,6 +675,13 @@ __global__ __launch_bounds__(kBlock) void poker_step_kernel(const PulsePokerView
         }
         if (PH & PULSE_PH_ADVANCE) sto(v.is_done_out, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
     }
+    if (POLICY && pa.wave_done) {
+        // the roll-out's stop rule (trainGPU.py:27-33) rides on the chunk's last launch: every wavefront stores how many
+        // of its tables are done -- a plain store, summed on the host after an asynchronous copy (atomics onto shared
+        // counters cost this launch as much as the separate counting kernel they would replace)
+        const int c = __popcll(__ballot(done && j == 0));
+        if ((threadIdx.x & 63) == 0) pa.wave_done[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = (uint32_t)c;
+    }
     STAMP(10);  // state stores issued
 #if PULSE_STAMPS
     __builtin_amdgcn_s_waitcnt(0);                      // vmcnt(0): all stores acknowledged
@@ -1144,8 +1154,11 @@ long long g_rollout_calls = 0;
 struct PulseStopRule {
     hipStream_t side;
     hipEvent_t ready[2], copied[2];
-    unsigned long long* counts_dev;        // [2] cumulative per slot
+    unsigned long long* counts_dev;        // [2] cumulative per slot (counting kernel, pulse_stoprule_submit)
     unsigned long long* counts_host;       // [2] pinned
+    uint32_t* waves_dev;                   // [2][max_waves] per-wavefront done counts written by the roll-out's last launch
+    uint32_t* waves_host;                  // [2][max_waves] pinned
+    int max_waves; int waves_used[2];      // waves_used[slot] > 0: the slot's verdict comes from the wave counts
     unsigned long long seen[2];
     long long pending[2]; int n_pending;
     long long chunk;
@@ -1156,9 +1169,16 @@ namespace {
 bool stoprule_pop(PulseStopRule* h) {
     const long long c = h->pending[0];
     h->pending[0] = h->pending[1]; --h->n_pending;
-    const unsigned long long total = h->counts_host[c & 1];
-    const unsigned long long n_done = total - h->seen[c & 1];
-    h->seen[c & 1] = total;
+    const int slot = (int)(c & 1);
+    unsigned long long n_done = 0;
+    if (h->waves_used[slot] > 0) {
+        const uint32_t* w = h->waves_host + (size_t)slot * h->max_waves;
+        for (int i = 0; i < h->waves_used[slot]; ++i) n_done += w[i];
+    } else {
+        const unsigned long long total = h->counts_host[slot];
+        n_done = total - h->seen[slot];
+        h->seen[slot] = total;
+    }
     return (double)n_done > h->threshold * (double)h->n;
 }
 }  // namespace
@@ -1175,6 +1195,10 @@ int pulse_stoprule_create(int32_t n_tables, double threshold, void** out) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counts_dev), 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->counts_dev, 0, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->counts_host), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    h->max_waves = (int)(((long long)n_tables * 16 + 63) / 64) + 4;       // 16 lanes per table at most
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->waves_dev), 2 * (size_t)h->max_waves * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(h->waves_dev, 0, 2 * (size_t)h->max_waves * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->waves_host), 2 * (size_t)h->max_waves * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) { delete h; return pulse::fail_hip((int)e, "pulse_stoprule_create"); }
     h->counts_host[0] = h->counts_host[1] = 0;
     *out = h;
@@ -1186,33 +1210,48 @@ int pulse_stoprule_destroy(void* handle) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->side);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ready[i]); (void)hipEventDestroy(h->copied[i]); }
-    (void)hipFree(h->counts_dev); (void)hipHostFree(h->counts_host); (void)hipStreamDestroy(h->side);
+    (void)hipFree(h->counts_dev); (void)hipHostFree(h->counts_host); (void)hipFree(h->waves_dev); (void)hipHostFree(h->waves_host);
+    (void)hipStreamDestroy(h->side);
     delete h;
     return 0;
 }
 
-int pulse_stoprule_submit(void* handle, const uint8_t* is_done, void* stream) {
-    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
-    if (!h || !is_done) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_submit: null argument");
-    hipStream_t st = (hipStream_t)stream;
-    while (h->n_pending >= 2) {                            // bounded run-ahead: never reuse a slot still in flight
+namespace {
+void stoprule_make_room(PulseStopRule* h) {                // bounded run-ahead: never reuse a slot still in flight
+    while (h->n_pending >= 2) {
         (void)hipEventSynchronize(h->copied[h->pending[0] & 1]);
         h->late_over = stoprule_pop(h) || h->late_over;
     }
+}
+// n_waves > 0: the roll-out's last launch has stored its per-wavefront counts in the slot; 0: count with the kernel
+int stoprule_submit(PulseStopRule* h, const uint8_t* is_done, hipStream_t st, int n_waves) {
+    stoprule_make_room(h);
     const int slot = (int)(h->chunk & 1);
-    if (h->n > 0) {
+    h->waves_used[slot] = n_waves;
+    if (h->n > 0 && n_waves == 0) {
         const int grid = min(1024, (h->n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(poker_stats_kernel, dim3(grid), dim3(kBlock), 0, st, is_done, (const float*)nullptr, (const uint8_t*)nullptr, h->n,
                            h->counts_dev + slot, (double*)nullptr);
     }
     hipError_t e = hipEventRecord(h->ready[slot], st);
     if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ready[slot], 0);
-    if (e == hipSuccess) e = hipMemcpyAsync(h->counts_host + slot, h->counts_dev + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->side);
+    if (e == hipSuccess) {
+        if (n_waves > 0) e = hipMemcpyAsync(h->waves_host + (size_t)slot * h->max_waves, h->waves_dev + (size_t)slot * h->max_waves,
+                                            (size_t)n_waves * sizeof(uint32_t), hipMemcpyDeviceToHost, h->side);
+        else e = hipMemcpyAsync(h->counts_host + slot, h->counts_dev + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->side);
+    }
     if (e == hipSuccess) e = hipEventRecord(h->copied[slot], h->side);
     if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_stoprule_submit");
     h->pending[h->n_pending++] = h->chunk;
     ++h->chunk;
     return 0;
+}
+}  // namespace
+
+int pulse_stoprule_submit(void* handle, const uint8_t* is_done, void* stream) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h || !is_done) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_submit: null argument");
+    return stoprule_submit(h, is_done, (hipStream_t)stream, 0);
 }
 
 int pulse_stoprule_over(void* handle, int32_t blocking, int32_t* over) {
@@ -1258,16 +1297,21 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
         }
         (void)hipEventRecord(g_ev_start[g_ev_used], st);
     }
+    PulseStopRule* rule = static_cast<PulseStopRule*>(stoprule);
+    const int n_waves = (int)(((long long)v_even->n_games * lanes_per_table() + 63) / 64);
+    const bool ride = rule && n_steps > 0 && n_waves <= rule->max_waves && rule->n == v_even->n_games;
+    if (ride) stoprule_make_room(rule);                    // the slot must be free before the last launch writes into it
     for (int i = 0; i < n_steps; ++i) {
         const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
         float* rw = (i & 1) ? rewards_odd : rewards_even;
-        const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0};
+        PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0, nullptr};
+        if (ride && i == n_steps - 1) pa.wave_done = rule->waves_dev + (size_t)(rule->chunk & 1) * rule->max_waves;
         launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
     }
     if (timed) { (void)hipEventRecord(g_ev_stop[g_ev_used], st); g_ev_launches[g_ev_used] = n_steps; ++g_ev_used; }
     if (stoprule && n_steps > 0) {                         // the done flags of the state the last launch produced
         const PulsePokerView& last = ((n_steps - 1) & 1) ? *v_odd : *v_even;
-        if (int rc = pulse_stoprule_submit(stoprule, last.is_done_out, stream)) return rc;
+        if (int rc = stoprule_submit(rule, last.is_done_out, st, ride ? n_waves : 0)) return rc;
     }
     return finish_launch("pulse_poker_rollout");
 }
