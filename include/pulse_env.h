@@ -235,7 +235,9 @@ typedef struct PulseQTable {
     double* values;
     uint64_t capacity, region_slots;
 } PulseQTable;
-/* state lookup/insert + epsilon-greedy: actions int64[B] out, slots int64[B] out (-1 = region full) */
+/* state lookup/insert + epsilon-greedy: actions int64[B] out, slots int64[B] out (-1 = no room: the region is full or
+ * 4,096 consecutive slots were taken -- size a shared table for the states a run will visit; such a board acts at
+ * random and is not updated) */
 int pulse_qtable_select(const PulseQTable* q, const int32_t* boards, int32_t n_boards, int32_t n, double epsilon,
                         uint64_t seed, uint64_t board_id0, uint64_t step_counter, int64_t* actions, int64_t* slots,
                         void* stream);

@@ -49,10 +49,15 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// Slot of `key` inside [base, base + slots): inserted (value row already zero) if absent.  -1 = region full.
+// Slot of `key` inside [base, base + slots): inserted (value row already zero) if absent.  -1 = no room.
+// At most kMaxProbe slots are examined: a table filled to the brim would otherwise turn every lookup of every
+// thread into a walk over the whole table (262,144 threads x 2^24 slots: a launch that never ends); past the
+// limit the state counts as "no room" like a full region.
+constexpr uint64_t kMaxProbe = 4096;
 __device__ __forceinline__ long long find_or_insert(unsigned long long* keys, uint64_t base, uint64_t slots, uint64_t key) {
     uint64_t h = mix64(key) & (slots - 1);
-    for (uint64_t probe = 0; probe < slots; ++probe) {
+    const uint64_t limit = slots < kMaxProbe ? slots : kMaxProbe;
+    for (uint64_t probe = 0; probe < limit; ++probe) {
         const uint64_t s = base + ((h + probe) & (slots - 1));
         unsigned long long cur = keys[s];
         if (cur == key) return (long long)s;

@@ -40,6 +40,7 @@ class Particle2D(_EnvBase):
         self.state = torch.zeros((batch_size, 4), device=device)
         self.terminated = torch.zeros(batch_size, device=device, dtype=torch.bool)
         self.steps = torch.zeros(batch_size, device=device, dtype=torch.int32)
+        self._truncated = torch.zeros(batch_size, device=device, dtype=torch.bool)     # constant (Particle2D.py:30)
 
     def reset(self, seed=None, options=None):                       # Particle2D.py:15-20
         if seed is not None:
@@ -64,4 +65,4 @@ class Particle2D(_EnvBase):
                                                       self.batch_size, float(self.dt), int(self.max_steps),
                                                       torch.cuda.current_stream(self.device).cuda_stream), "pulse_particle2d_step")
         self.terminated = terminated
-        return obs, rewards, self.terminated, torch.zeros_like(self.terminated), {}
+        return obs, rewards, self.terminated, self._truncated, {}

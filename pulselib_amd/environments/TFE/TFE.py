@@ -41,6 +41,7 @@ class TFEBatch:
         self.total_score = torch.zeros(batch_size, dtype=torch.int64, device=device)
         self.rewards = torch.zeros(batch_size, dtype=torch.int32, device=device)
         self.dones = torch.zeros(batch_size, dtype=torch.bool, device=device)
+        self.truncated = torch.zeros(batch_size, dtype=torch.bool, device=device)      # constant: never truncates (TFE.py:189)
         self.step_counter = 0
 
     def _stream(self):
@@ -64,7 +65,7 @@ class TFEBatch:
         _native.check(self._lib.pulse_tfe_step(self.boards.data_ptr(), self.total_score.data_ptr(), actions.data_ptr(),
                                                self.rewards.data_ptr(), self.dones.data_ptr(), self.batch_size, self.n,
                                                self.seed, self.board_id0, self.step_counter, self._stream()), "pulse_tfe_step")
-        return self.boards, self.rewards, self.dones, torch.zeros_like(self.dones), {"score": self.total_score}
+        return self.boards, self.rewards, self.dones, self.truncated, {"score": self.total_score}
 
 
 class TFE(_EnvBase):
