@@ -228,8 +228,8 @@ constexpr int kLd = 33;
 
 struct CoopLds {                 // offsets in floats into the dynamic LDS block
     static constexpr int Xs = 0, A1 = Xs + 64 * kLd, A2 = A1 + 128 * kLd, A3 = A2 + 128 * kLd, A4 = A3 + 64 * kLd,
-                         P = A4 + 32 * kLd,                    // 3 x 16 x 64 partial sums
-                         List = P + 3 * 16 * 64,               // 256 row ids + 8 counters
+                         P = A4 + 32 * kLd,                    // 2 x (3 x 16 x 64) partial sums (two networks in flight in training)
+                         List = P + 2 * 3 * 16 * 64,           // 256 row ids + 8 counters
                          Tgt = List + 264,                     // 32 TD targets
                          EndEval = Tgt + 32,
                          G1 = EndEval, G2 = G1 + 128 * kLd, G3 = G2 + 128 * kLd, G4 = G3 + 64 * kLd,
@@ -325,13 +325,13 @@ __device__ __forceinline__ void coop_epilogue(const f32x16& acc, const float* __
 }
 
 // 32 rows of `x` (row ids per column in `rowc`, < 0 = padding) -> Xs[k][column], zero above state_dim; all 4 wavefronts
-__device__ __forceinline__ void coop_load_rows(float* __restrict__ lds, const float* __restrict__ x, long long stride, int K1, int rowc,
+__device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const float* __restrict__ x, long long stride, int K1, int rowc,
                                                int wv, int c, int h) {
     const float* xr = x + (size_t)max(rowc, 0) * stride;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 16 * wv + 8 * h + j;
-        lds[CoopLds::Xs + k * kLd + c] = (rowc >= 0 && k < K1) ? xr[k] : 0.0f;
+        dst[k * kLd + c] = (rowc >= 0 && k < K1) ? xr[k] : 0.0f;
     }
 }
 
@@ -394,6 +394,80 @@ __device__ __forceinline__ f32x16 coop_forward(const PulseQNet& n, float* __rest
     return qv;
 }
 
+// Training: the target network on s' (eval) and the network on s (train mode) taken through the layers TOGETHER -- every
+// stage issues both networks' MFMAs and epilogues between one pair of barriers, so the two forwards cost 7 barrier
+// phases instead of 14.  The target's activations borrow the backward pass's delta buffers (free until then):
+// x' and a'_2, a'_4 in Db, a'_1 and a'_3 in Da.  q_tgt / q come back in wavefront 0.
+template <bool VEC>
+__device__ __forceinline__ void coop_forward_pair(const PulseQNet& nt, const PulseQNet& n, float* __restrict__ lds, int wv, int c, int h,
+                                                  uint64_t seed, uint64_t gid, uint64_t step, uint32_t thr, float scale, f32x16& q_tgt,
+                                                  f32x16& q) {
+    float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
+    float* A4 = lds + CoopLds::A4; float* P = lds + CoopLds::P; float* P2 = P + 3 * 16 * 64;
+    float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
+    float* Xn = lds + CoopLds::Db; float* T1 = lds + CoopLds::Da; float* T2 = lds + CoopLds::Db; float* T3 = lds + CoopLds::Da;
+    float* T4 = lds + CoopLds::Db;
+    const int lane = c + 32 * h, K1 = n.state_dim, K1r = (K1 + 7) & ~7;
+    __syncthreads();                                                          // Xs, Xn complete
+    {   // layer 1
+        const f32x16 at = dense_lds<VEC, 8>(nt.w1, K1, 32 * wv + c, c, h, Xn, 0, K1r);
+        const f32x16 ac = dense_lds<VEC, 8>(n.w1, K1, 32 * wv + c, c, h, Xs, 0, K1r);
+        coop_epilogue<false>(at, nt.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, T1, nullptr);
+        coop_epilogue<true>(ac, n.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, G1);
+    }
+    __syncthreads();
+    {   // layer 2 (+ Dropout on the training side, Player.py:194)
+        const f32x16 at = dense_lds<true, 16>(nt.w2, 128, 32 * wv + c, c, h, T1, 0, 128);
+        const f32x16 ac = dense_lds<true, 16>(n.w2, 128, 32 * wv + c, c, h, A1, 0, 128);
+        coop_epilogue<false>(at, nt.b2, 32 * wv, c, h, 0xFFFFu, 1.0f, T2, nullptr);
+        coop_epilogue<true>(ac, n.b2, 32 * wv, c, h, dropout_keep_bits(seed, gid, step, wv, h, thr), scale, A2, G2);
+    }
+    __syncthreads();
+    {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197)
+        const int ot = wv & 1, half = wv >> 1;
+        f32x16 at = dense_lds<true, 8>(nt.w3, 128, 32 * ot + c, c, h, T2, 64 * half, 64 * half + 64);
+        f32x16 ac = dense_lds<true, 8>(n.w3, 128, 32 * ot + c, c, h, A2, 64 * half, 64 * half + 64);
+        if (half == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { P[(ot * 16 + r) * 64 + lane] = at[r]; P2[(ot * 16 + r) * 64 + lane] = ac[r]; }
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { at[r] += P[(ot * 16 + r) * 64 + lane]; ac[r] += P2[(ot * 16 + r) * 64 + lane]; }
+            coop_epilogue<false>(at, nt.b3, 32 * ot, c, h, 0xFFFFu, 1.0f, T3, nullptr);
+            coop_epilogue<true>(ac, n.b3, 32 * ot, c, h, dropout_keep_bits(seed, gid, step, 4 + ot, h, thr), scale, A3, G3);
+        }
+    }
+    __syncthreads();
+    {   // layer 4: one output tile, k in quarters
+        f32x16 at = dense_lds<true, 2>(nt.w4, 64, c, c, h, T3, 16 * wv, 16 * wv + 16);
+        f32x16 ac = dense_lds<true, 2>(n.w4, 64, c, c, h, A3, 16 * wv, 16 * wv + 16);
+        if (wv > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { P[((wv - 1) * 16 + r) * 64 + lane] = at[r]; P2[((wv - 1) * 16 + r) * 64 + lane] = ac[r]; }
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                at[r] += (P[r * 64 + lane] + P[(16 + r) * 64 + lane]) + P[(32 + r) * 64 + lane];
+                ac[r] += (P2[r * 64 + lane] + P2[(16 + r) * 64 + lane]) + P2[(32 + r) * 64 + lane];
+            }
+            coop_epilogue<false>(at, nt.b4, 0, c, h, 0xFFFFu, 1.0f, T4, nullptr);
+            coop_epilogue<true>(ac, n.b4, 0, c, h, 0xFFFFu, 1.0f, A4, G4);
+        }
+    }
+    __syncthreads();
+    q_tgt = zero16(); q = zero16();
+    if (wv == 0) {
+        q_tgt = dense_lds<true, 4>(nt.w5, 32, min(c, n.n_actions - 1), c, h, T4, 0, 32);
+        bias_act<false>(q_tgt, nt.b5, 0, n.n_actions, h);
+        q = dense_lds<true, 4>(n.w5, 32, min(c, n.n_actions - 1), c, h, A4, 0, 32);
+        bias_act<false>(q, n.b5, 0, n.n_actions, h);
+    }
+}
+
 // 256 candidate rows -> ids of the selected ones in List[0..count), count returned to every thread
 __device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, int row) {
     int* list = reinterpret_cast<int*>(lds + CoopLds::List);
@@ -425,7 +499,7 @@ __global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
     for (int t0 = 0; t0 < count; t0 += 32) {
         const int rowc = t0 + c < count ? list[t0 + c] : -1;
         __syncthreads();                                                      // previous tile's readers are done
-        coop_load_rows(lds, a.states, a.row_stride, a.net.state_dim, rowc, wv, c, h);
+        coop_load_rows(lds + CoopLds::Xs, a.states, a.row_stride, a.net.state_dim, rowc, wv, c, h);
         const f32x16 qv = coop_forward<false, VEC>(a.net, lds, wv, c, h, 0, 0, 0, 0, 1.0f);
         if (wv == 0) {
             const bool live = rowc >= 0;
@@ -535,7 +609,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     const int K1 = n.state_dim, A = n.n_actions;
     const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
-    float* A4 = lds + CoopLds::A4; float* Tgt = lds + CoopLds::Tgt;
+    float* A4 = lds + CoopLds::A4;
     float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
     float* Da = lds + CoopLds::Da; float* Db = lds + CoopLds::Db;
     const size_t o_b1 = (size_t)128 * K1, o_w2 = o_b1 + 128, o_b2 = o_w2 + 128 * 128, o_w3 = o_b2 + 128, o_b3 = o_w3 + 64 * 128,
@@ -583,34 +657,28 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             const bool live = rowc >= 0;
             const int rw = max(rowc, 0);
             const uint64_t gid = a.table_id0 + (uint64_t)rw;
-            // target: r + gamma * max_a' Q_target(s', a') * (1 - done)                               (:275-277)
+            // both forwards together: target r + gamma * max_a' Q_target(s', a') * (1 - done) (:275-277), network in train mode
             __syncthreads();
             QSTAMP(1);
-            coop_load_rows(lds, a.next_states, a.next_stride, K1, rowc, wv, c, h);
+            coop_load_rows(lds + CoopLds::Db, a.next_states, a.next_stride, K1, rowc, wv, c, h);
+            coop_load_rows(lds + CoopLds::Xs, a.states, a.stride, K1, rowc, wv, c, h);
             {
-                const f32x16 qn = coop_forward<false, VEC>(a.tgt, lds, wv, c, h, 0, 0, 0, 0, 1.0f);
-                if (wv == 0) {
+                f32x16 qn, qv;
+                coop_forward_pair<VEC>(a.tgt, n, lds, wv, c, h, a.seed, gid, a.step, thr, scale, qn, qv);
+                QSTAMP(2);
+                if (wv == 0) {                                                // delta_5 and the loss terms (:270-279)
                     float best = -INFINITY;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) if (rho(r) + 4 * h < A) best = fmaxf(best, qn[r]);
                     best = fmaxf(best, __shfl_xor(best, 32));
                     const float notdone = (live && a.dones[rw]) ? 0.0f : 1.0f;
-                    if (h == 0) Tgt[c] = (live ? a.rewards[rw] : 0.0f) + a.gamma * best * notdone;
-                }
-            }
-            __syncthreads();
-            QSTAMP(2);
-            // forward, train mode
-            coop_load_rows(lds, a.states, a.stride, K1, rowc, wv, c, h);
-            {
-                const f32x16 qv = coop_forward<true, VEC>(n, lds, wv, c, h, a.seed, gid, a.step, thr, scale);
-                if (wv == 0) {                                                // delta_5 and the loss terms (:270-279)
+                    const float target = (live ? a.rewards[rw] : 0.0f) + a.gamma * best * notdone;
                     const int act = live ? (int)a.actions[rw] : -1;
                     float qa = 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) qa += (rho(r) + 4 * h == act) ? qv[r] : 0.0f;
                     qa += __shfl_xor(qa, 32);
-                    const float td = live ? qa - Tgt[c] : 0.0f;
+                    const float td = live ? qa - target : 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Da[(rho(r) + 4 * h) * kLd + c] = (rho(r) + 4 * h == act) ? 2.0f * td : 0.0f;
                     float sq = (h == 0) ? td * td : 0.0f, cnt = (h == 0 && live) ? 1.0f : 0.0f;

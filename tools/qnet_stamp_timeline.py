@@ -30,7 +30,7 @@ r = torch.randn((N,), generator=g).to(dev)
 d = (torch.rand((N,), generator=g) < 0.3).to(dev)
 m = (torch.rand((N,), generator=g) < frac).to(dev)
 buf = torch.zeros((256, 16), dtype=torch.int64, device=dev)
-names = ["compaction", "target forward", "train forward", "layer 5 bwd", "layer 4 bwd", "layer 3 bwd", "layer 2 bwd", "layer 1 bwd",
+names = ["compaction", "both forwards", "delta_5", "layer 5 bwd", "layer 4 bwd", "layer 3 bwd", "layer 2 bwd", "layer 1 bwd",
          "bias + stats store"]
 for rep in range(3):
     q.train_step_native(s, a, r, ns, d, m)
