@@ -275,8 +275,9 @@ int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride
  * workgroups' slices; (3) gradient mean / clip_grad_norm_ / AdamW / target sync, elementwise.
  * The network and its target each live in ONE flat fp32 buffer of pulse_qnet_param_count() floats laid out
  * w1,b1,w2,b2,w3,b3,w4,b4,w5,b5 (torch layouts); `net` / `target` hold the ten views.  grad, exp_avg, exp_avg_sq: flat
- * buffers of the same length (moments zero before the first call).  partials: device fp32[max_blocks * (n_params + 4)]
- * scratch (max_blocks = number of persistent workgroups, 256 = one per CU).  step: device int64 optimizer step count
+ * buffers of the same length (moments zero before the first call).  partials: device fp32[max_blocks *
+ * pulse_qnet_slice_floats()] scratch (max_blocks = number of persistent workgroups, 256 = one per CU; a workgroup's
+ * slice is laid out for its own stores, not in parameter order).  step: device int64 optimizer step count
  * (bias correction, target sync every update_freq steps).  stats: device fp32[4] scratch.  report: device fp32[4] out:
  * [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping.
  * Row filter: row_mask[r] != 0 (NULL: all) and states[r][12] in {0, 2} (:261); if no row passes, nothing changes (:262).
@@ -295,6 +296,7 @@ typedef struct PulseQNetTrain {
     int32_t update_freq, max_blocks;
 } PulseQNetTrain;
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions);
+int pulse_qnet_slice_floats(void);
 int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter,

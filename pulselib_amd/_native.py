@@ -108,6 +108,7 @@ SYMBOLS = {
     "pulse_qnet_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P, _P, _P]),
     "pulse_qnet_param_count": (C.c_int, [_I32, _I32]),
+    "pulse_qnet_slice_floats": (C.c_int, []),
     "pulse_qnet_train_step": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I32, _U64, _U64, _U64, _P, _P, _P]),
     "pulse_qnet_train_grads": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I32, _U64, _U64, _U64, _P, _P, _P]),
     "pulse_qnet_train_apply": (C.c_int, [_P, _P]),

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
 // (qnet_adamw_kernel) is mean / clip_grad_norm_ / AdamW / target sync, elementwise over the parameters.
 struct TrainArgs {
     PulseQNet net, tgt;
-    float* partials;                          // [gridDim.x][n_params + 4]: gradient sums, then {rows, sum td^2, sum reward, -}
+    float* partials;                          // [gridDim.x][kSlicePitch]: gradient blocks, biases, then {rows, sum td^2, sum reward, -}
     float* scal;                              // scal[0] = squared gradient norm of the reduce launch: cleared here for it
     int n_params;
     const float* states; long long stride;
@@ -557,10 +557,18 @@ struct TrainArgs {
     float gamma, drop_p;
 };
 
-// block (ot, it) of dW += delta . a^T for this tile, into the workgroup's own slice (plain read-modify-write: a block
-// of a slice belongs to one wavefront for the whole launch; `first` = nothing accumulated yet); delta in D, a_{l-1} in
-// Ap; bsum: this tile's db rows of tile ot
-__device__ __forceinline__ void dw_accum(const float* __restrict__ D, const float* __restrict__ Ap, float* __restrict__ gw, int n_out, int n_in,
+// A workgroup's gradient slice is private scratch, so its layout is the accumulators' own: 35 blocks of 32x32 (layer 1:
+// 4x2, layer 2: 4x4, layer 3: 2x4, layer 4: 1x2, layer 5: 1x1 -- padded rows / columns included), each stored as
+// [lane][16 registers], then the five bias vectors, then 4 statistics.  A wavefront then writes a block with four
+// 16-byte stores per lane instead of sixteen 4-byte ones (global stores are issue-bound: the dword form made the
+// weight-gradient blocks 4x slower than their MFMAs); qnet_grad_reduce_kernel maps parameters to this layout.
+constexpr int kSliceBlk1 = 0, kSliceBlk2 = 8, kSliceBlk3 = 24, kSliceBlk4 = 32, kSliceBlk5 = 34, kSliceBlocks = 35;
+constexpr int kSliceBias = kSliceBlocks * 1024;                 // b1 @+0, b2 @+128, b3 @+256, b4 @+320, b5 @+352 (32 slots)
+constexpr int kSliceStats = kSliceBias + 384, kSlicePitch = kSliceStats + 4;
+
+// block `blk` (= dW rows [32 ot, +32) x columns [32 it, +32) of its layer) += delta . a^T for this tile (`first`: nothing
+// accumulated yet); delta in D, a_{l-1} in Ap; bsum: this tile's db rows of tile ot
+__device__ __forceinline__ void dw_accum(const float* __restrict__ D, const float* __restrict__ Ap, float* __restrict__ slice, int blk,
                                          int ot, int it, int c, int h, bool first, float* bsum) {
     float ad[16]; float bs = 0.0f;
 #pragma unroll
@@ -569,15 +577,34 @@ __device__ __forceinline__ void dw_accum(const float* __restrict__ D, const floa
     f32x16 acc = zero16();
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s2], Ap[(32 * it + c) * kLd + 2 * s2 + h], acc, 0, 0, 0);
-    const int in = 32 * it + c;
+    float4* dst = reinterpret_cast<float4*>(slice + (size_t)blk * 1024 + (size_t)(c + 32 * h) * 16);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = 32 * ot + rho(r) + 4 * h;
-        if (o < n_out && in < n_in) {
-            float* p = gw + (size_t)o * n_in + in;
-            *p = first ? acc[r] : *p + acc[r];
-        }
+    for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if (!first) { const float4 o = dst[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        dst[q] = v;
     }
+}
+
+// offset of parameter i (flat order w1,b1,...,w5,b5) inside a slice
+__device__ __forceinline__ int slice_offset(int i, int K1, int A) {
+    const int n_out[5] = {128, 128, 64, 32, A}, n_in[5] = {K1, 128, 128, 64, 32};
+    const int blk0[5] = {kSliceBlk1, kSliceBlk2, kSliceBlk3, kSliceBlk4, kSliceBlk5}, its[5] = {2, 4, 4, 2, 1};
+    const int bias0[5] = {0, 128, 256, 320, 352};
+    int base = 0;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        const int nw = n_out[l] * n_in[l];
+        if (i < base + nw) {
+            const int o = (i - base) / n_in[l], in = (i - base) - o * n_in[l];
+            const int ro = o & 31, hh = (ro >> 2) & 1, r = (ro & 3) + 4 * (ro >> 3);
+            return (blk0[l] + (o >> 5) * its[l] + (in >> 5)) * 1024 + ((in & 31) + 32 * hh) * 16 + r;
+        }
+        base += nw;
+        if (i < base + n_out[l]) return kSliceBias + bias0[l] + (i - base);
+        base += n_out[l];
+    }
+    return kSliceStats;                                              // not reached for i < n_params
 }
 
 // tile `it` of delta_{l-1} = (W^T . delta_l) * g_{l-1} -> Dn[32 it ..]; W is n_out x n_in, delta_l = units [0, KU) of D.
@@ -612,8 +639,6 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     float* A4 = lds + CoopLds::A4;
     float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
     float* Da = lds + CoopLds::Da; float* Db = lds + CoopLds::Db;
-    const size_t o_b1 = (size_t)128 * K1, o_w2 = o_b1 + 128, o_b2 = o_w2 + 128 * 128, o_w3 = o_b2 + 128, o_b3 = o_w3 + 64 * 128,
-                 o_w4 = o_b3 + 64, o_b4 = o_w4 + 32 * 64, o_w5 = o_b4 + 32, o_b5 = o_w5 + (size_t)A * 32;
     const uint32_t thr = (uint32_t)(a.drop_p * 65536.0f);
     const float scale = 1.0f / (1.0f - a.drop_p);
 
@@ -622,7 +647,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     float rows_sum = 0.0f, sq_sum = 0.0f;                        // wavefront 0, lane-replicated after the reductions
     float reward_sum = 0.0f;                                     // this wavefront's candidate rows
     bool used = false;
-    float* part = a.partials + (size_t)blockIdx.x * (a.n_params + 4);
+    float* part = a.partials + (size_t)blockIdx.x * kSlicePitch;
 
     // scal[0] is read by every workgroup of the previous step's AdamW launch and accumulated by this step's reduce
     // launch: this kernel sits between the two on the stream, so its first thread clears it
@@ -690,51 +715,55 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             __syncthreads();
             QSTAMP(3);
             // layer 5 (delta_5 in Da): dW5 | delta_4 -> Db
-            if (wv == 0) dw_accum(Da, A4, part_t + o_w5, A, 32, 0, 0, c, h, first, &b5);
+            if (wv == 0) dw_accum(Da, A4, part_t, kSliceBlk5, 0, 0, c, h, first, &b5);
             if (wv == 1) back_block<32>(n.w5, A, 32, 0, Da, G4, Db, c, h);
             __syncthreads();
             QSTAMP(4);
             // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
-            if (wv == 0) dw_accum(Db, A3, part_t + o_w4, 32, 64, 0, 0, c, h, first, &b4);
-            if (wv == 1) dw_accum(Db, A3, part_t + o_w4, 32, 64, 0, 1, c, h, first, nullptr);
+            if (wv == 0) dw_accum(Db, A3, part_t, kSliceBlk4 + 0, 0, 0, c, h, first, &b4);
+            if (wv == 1) dw_accum(Db, A3, part_t, kSliceBlk4 + 1, 0, 1, c, h, first, nullptr);
             if (wv >= 2) back_block<32>(n.w4, 32, 64, wv - 2, Db, G3, Da, c, h);
             __syncthreads();
             QSTAMP(5);
             // layer 3 (delta_3 in Da): 8 dW blocks, column tile wv of both row tiles | delta_2 tile wv -> Db
-            dw_accum(Da, A2, part_t + o_w3, 64, 128, 0, wv, c, h, first, wv == 0 ? &b3 : nullptr);
-            dw_accum(Da, A2, part_t + o_w3, 64, 128, 1, wv, c, h, first, wv == 1 ? &b3 : nullptr);
+            dw_accum(Da, A2, part_t, kSliceBlk3 + wv, 0, wv, c, h, first, wv == 0 ? &b3 : nullptr);
+            dw_accum(Da, A2, part_t, kSliceBlk3 + 4 + wv, 1, wv, c, h, first, wv == 1 ? &b3 : nullptr);
             back_block<64>(n.w3, 64, 128, wv, Da, G2, Db, c, h);
             __syncthreads();
             QSTAMP(6);
             // layer 2 (delta_2 in Db): 16 dW blocks, column tile wv of each row tile | delta_1 tile wv -> Da
-#pragma unroll 1
-            for (int ot = 0; ot < 4; ++ot) dw_accum(Db, A1, part_t + o_w2, 128, 128, ot, wv, c, h, first, ot == wv ? &b2 : nullptr);
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) dw_accum(Db, A1, part_t, kSliceBlk2 + 4 * ot + wv, ot, wv, c, h, first, ot == wv ? &b2 : nullptr);
+            QSTAMP(10);
             back_block<128>(n.w2, 128, 128, wv, Db, G1, Da, c, h);
+            QSTAMP(11);
             __syncthreads();
             QSTAMP(7);
             // layer 1 (delta_1 in Da): row tile wv x the two column tiles of the input
-            dw_accum(Da, Xs, part_t + 0, 128, K1, wv, 0, c, h, first, &b1);
-            if (K1 > 32) dw_accum(Da, Xs, part_t + 0, 128, K1, wv, 1, c, h, first, nullptr);
+            dw_accum(Da, Xs, part_t, kSliceBlk1 + 2 * wv, wv, 0, c, h, first, &b1);
+            if (K1 > 32) dw_accum(Da, Xs, part_t, kSliceBlk1 + 2 * wv + 1, wv, 1, c, h, first, nullptr);
         }
     }
 
     QSTAMP(8);
     if (!used) {                                                  // no valid row in any of this workgroup's windows: a zero slice
-        for (int i = threadIdx.x; i < a.n_params; i += 256) part[i] = 0.0f;
+        for (int i = threadIdx.x; i < kSliceStats; i += 256) part[i] = 0.0f;
+    } else if (K1 <= 32) {                                        // the second column tile of layer 1 was never touched
+        for (int i = threadIdx.x; i < 4 * 1024; i += 256) part[(size_t)(kSliceBlk1 + 2 * (i >> 10) + 1) * 1024 + (i & 1023)] = 0.0f;
     }
     // db rows: every bias is written by exactly one wavefront
     if (used && h0 == 0) {
-        if (wv == 0) { if (c0 < A) part[o_b5 + c0] = b5; part[o_b4 + c0] = b4; }
-        if (wv < 2) part[o_b3 + 32 * wv + c0] = b3;
-        part[o_b2 + 32 * wv + c0] = b2;
-        part[o_b1 + 32 * wv + c0] = b1;
+        if (wv == 0) { part[kSliceBias + 352 + c0] = b5; part[kSliceBias + 320 + c0] = b4; }
+        if (wv < 2) part[kSliceBias + 256 + 32 * wv + c0] = b3;
+        part[kSliceBias + 128 + 32 * wv + c0] = b2;
+        part[kSliceBias + 32 * wv + c0] = b1;
     }
     float* wave_reward = lds + CoopLds::List + 260;               // 4 spare words behind the compaction counters
     __syncthreads();
     if (lane == 0) wave_reward[wv] = reward_sum;
     __syncthreads();
     if (wv == 0 && lane == 0) {
-        float* ps = part + a.n_params;
+        float* ps = part + kSliceStats;
         ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = (wave_reward[0] + wave_reward[1]) + (wave_reward[2] + wave_reward[3]);
         ps[3] = used ? 1.0f : 0.0f;
     }
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
 // Launch 2: flat gradient = sum of the used slices; scal[0] += its squared norm (one atomic per workgroup); workgroup 0
 // also totals the row count / squared TD error / reward and advances the optimizer step when there is something to learn.
 struct ReduceArgs {
-    const float* partials; int n_blocks, n_params;
+    const float* partials; int n_blocks, n_params, state_dim, n_actions;
     float* grad; float* scal;                 // scal: [0] sum g^2 (zeroed here by the previous step's AdamW), [1] rows, [2] sum td^2
     long long* step; double* reward_sum;      // reward_sum: nullptr or += sum of rewards over row_mask rows
 };
@@ -752,10 +781,10 @@ struct ReduceArgs {
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a) {
     __shared__ float red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const size_t pitch = (size_t)a.n_params + 4;
+    const size_t pitch = (size_t)kSlicePitch;
     float g = 0.0f;
     if (i < a.n_params) {
-        const float* p = a.partials + i;
+        const float* p = a.partials + slice_offset(i, a.state_dim, a.n_actions);
         int b = 0;
         for (; b + 8 <= a.n_blocks; b += 8) {                 // eight independent loads in flight per thread
             float v[8];
@@ -776,7 +805,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         float rows = 0.0f, sq = 0.0f; double rew = 0.0;
         for (int b = threadIdx.x; b < a.n_blocks; b += 64) {
-            const float* ps = a.partials + b * pitch + a.n_params;
+            const float* ps = a.partials + b * pitch + kSliceStats;
             rows += ps[0]; sq += ps[1]; rew += (double)ps[2];
         }
 #pragma unroll
@@ -887,6 +916,8 @@ int pulse_debug_set_qnet_stamp_buffer(unsigned long long* buf) {
 }
 #endif
 
+int pulse_qnet_slice_floats(void) { return kSlicePitch; }
+
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions) {
     if (state_dim < 1 || n_actions < 1 || n_actions > 32) return pulse::fail(PULSE_EINVAL, "pulse_qnet_param_count: bad dimensions");
     return 128 * state_dim + 128 + 128 * 128 + 128 + 64 * 128 + 64 + 32 * 64 + 32 + 32 * n_actions + n_actions;
@@ -945,7 +976,8 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     if (vec) hipLaunchKernelGGL((qnet_train_kernel<true>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
     else hipLaunchKernelGGL((qnet_train_kernel<false>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
     ReduceArgs r{};
-    r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.grad = t->grad; r.scal = t->stats;
+    r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
+        r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
     r.reward_sum = reward_sum;
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(eg), dim3(256), 0, st, r);

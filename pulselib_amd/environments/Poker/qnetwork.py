@@ -179,7 +179,8 @@ class PokerQNetwork(nn.Module):
                 "step": torch.zeros(1, dtype=torch.int64, device=dev),
                 "stats": torch.zeros(4, dtype=torch.float32, device=dev),
                 "report": torch.zeros(4, dtype=torch.float32, device=dev),
-                "partials": torch.empty(TRAIN_BLOCKS * (n + 4), dtype=torch.float32, device=dev),   # 33 MB at 256 workgroups
+                "partials": torch.empty(TRAIN_BLOCKS * _native.lib().pulse_qnet_slice_floats(), dtype=torch.float32,
+                                        device=dev),                                            # 37 MB at 256 workgroups
             }
         t = _native.QNetTrain()
         t.net, t.target = self._net_struct(self.network), self._net_struct(self.target_network)

@@ -44,9 +44,11 @@ for rep in range(5):
     st = buf.cpu().numpy().astype(np.int64)
     st = st[st[:, 9] > 0]
     acc += np.diff(st[:, :10], axis=1).mean(axis=0)
+    extra = (st[:, 10] - st[:, 6]).mean(), (st[:, 11] - st[:, 10]).mean(), (st[:, 7] - st[:, 11]).mean()
     span = st[:, 9].max() - st[:, 0].min()
 lib.pulse_debug_set_qnet_stamp_buffer(None)
 acc /= 5
 print(f"N={N} mask fraction {frac}: kernel span {span} ticks; per workgroup (first... last tile overwrite): total {acc.sum():.0f}")
+print(f"   layer 2 bwd split: dW blocks {extra[0]:.0f}, delta_1 tile {extra[1]:.0f}, wait at barrier {extra[2]:.0f}")
 for n, c in zip(names, acc):
     print(f"   {n:22s} {c:9.0f}  {100 * c / acc.sum():5.1f} %")
