@@ -586,25 +586,31 @@ __device__ __forceinline__ void dw_accum(const float* __restrict__ D, const floa
     }
 }
 
-// offset of parameter i (flat order w1,b1,...,w5,b5) inside a slice
-__device__ __forceinline__ int slice_offset(int i, int K1, int A) {
+// flat parameter index (order w1,b1,...,w5,b5) of slice element j, or -1 for a padding element
+__device__ __forceinline__ int slice_param(int j, int K1, int A) {
     const int n_out[5] = {128, 128, 64, 32, A}, n_in[5] = {K1, 128, 128, 64, 32};
-    const int blk0[5] = {kSliceBlk1, kSliceBlk2, kSliceBlk3, kSliceBlk4, kSliceBlk5}, its[5] = {2, 4, 4, 2, 1};
-    const int bias0[5] = {0, 128, 256, 320, 352};
-    int base = 0;
+    const int blk0[6] = {kSliceBlk1, kSliceBlk2, kSliceBlk3, kSliceBlk4, kSliceBlk5, kSliceBlocks}, its[5] = {2, 4, 4, 2, 1};
+    const int bias0[6] = {0, 128, 256, 320, 352, 384};
+    int base[5], bbase[5], acc = 0;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) { base[l] = acc; acc += n_out[l] * n_in[l]; bbase[l] = acc; acc += n_out[l]; }
+    if (j >= kSliceBias) {
+        const int u = j - kSliceBias;
+#pragma unroll
+        for (int l = 0; l < 5; ++l)
+            if (u >= bias0[l] && u < bias0[l + 1]) return (u - bias0[l]) < n_out[l] ? bbase[l] + (u - bias0[l]) : -1;
+        return -1;
+    }
+    const int blk = j >> 10, lane = (j >> 4) & 63, r = j & 15, c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int l = 0; l < 5; ++l) {
-        const int nw = n_out[l] * n_in[l];
-        if (i < base + nw) {
-            const int o = (i - base) / n_in[l], in = (i - base) - o * n_in[l];
-            const int ro = o & 31, hh = (ro >> 2) & 1, r = (ro & 3) + 4 * (ro >> 3);
-            return (blk0[l] + (o >> 5) * its[l] + (in >> 5)) * 1024 + ((in & 31) + 32 * hh) * 16 + r;
+        if (blk >= blk0[l] && blk < blk0[l + 1]) {
+            const int b = blk - blk0[l], ot = b / its[l], it = b - ot * its[l];
+            const int o = 32 * ot + rho(r) + 4 * h, in = 32 * it + c;
+            return (o < n_out[l] && in < n_in[l]) ? base[l] + o * n_in[l] + in : -1;
         }
-        base += nw;
-        if (i < base + n_out[l]) return kSliceBias + bias0[l] + (i - base);
-        base += n_out[l];
     }
-    return kSliceStats;                                              // not reached for i < n_params
+    return -1;
 }
 
 // tile `it` of delta_{l-1} = (W^T . delta_l) * g_{l-1} -> Dn[32 it ..]; W is n_out x n_in, delta_l = units [0, KU) of D.
@@ -780,11 +786,12 @@ struct ReduceArgs {
 
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a) {
     __shared__ float red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;               // slice element: the workgroups' slices are read in their own order
     const size_t pitch = (size_t)kSlicePitch;
     float g = 0.0f;
-    if (i < a.n_params) {
-        const float* p = a.partials + slice_offset(i, a.state_dim, a.n_actions);
+    const int i = j < kSliceStats ? slice_param(j, a.state_dim, a.n_actions) : -1;
+    if (i >= 0) {
+        const float* p = a.partials + j;
         int b = 0;
         for (; b + 8 <= a.n_blocks; b += 8) {                 // eight independent loads in flight per thread
             float v[8];
@@ -977,10 +984,10 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     else hipLaunchKernelGGL((qnet_train_kernel<false>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
     ReduceArgs r{};
     r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
-        r.grad = t->grad; r.scal = t->stats;
+    r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
     r.reward_sum = reward_sum;
-    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3(eg), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3((unsigned)((kSliceStats + 255) / 256)), dim3(256), 0, st, r);
     }
     if (apply && (n_rows > 0 || !grads)) {
         AdamArgs b{};
