@@ -206,6 +206,8 @@ class PokerQNetwork(nn.Module):
         states, next_states = self._rows(states), self._rows(next_states)
         n = states.shape[0]
         t = self._native_state()
+        if n == 0:                            # nothing to learn from: the reference returns before the optimizer (:262)
+            return self._native["report"]
 
         def u8(x):
             if x is None:

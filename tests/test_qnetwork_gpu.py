@@ -362,3 +362,54 @@ def test_fused_trainer_with_hand_metrics_side_channel(g):
     # chips are conserved per table, so what the learner's seat won over the finished hands is what the episodes report
     assert abs(hm["final"]["total_bb_won"]) <= 100 * hm["final"]["total_hands"]
     assert set(hm["final"]["slices"]) == {"seat", "player_count", "street_depth"}
+
+
+@pytest.mark.parametrize("state_dim,n_actions", [(16, 4), (24, 32), (13, 1), (64, 13)])
+def test_native_kernels_other_shapes(state_dim, n_actions):
+    """The ABI promises state_dim 13..64 and n_actions 1..32 for training (1..4096 / 1..32 for inference): forward,
+    masked act and one training step against the oracle at the corners."""
+    from oracle import oracle as orc
+    from pulselib_amd.environments.Poker import PokerQNetwork
+    torch.manual_seed(state_dim * 100 + n_actions)
+    q = PokerQNetwork(None, torch.device(DEV), gamma=.9, update_freq=3, state_dim=state_dim, action_dim=n_actions, learning_rate=1e-3,
+                      weight_decay=1e-4, seed=8)
+    n = 700
+    rng = np.random.default_rng(state_dim)
+    s = (rng.standard_normal((n, state_dim)) * 2).astype(np.float32); s[:, 12] = rng.integers(0, 4, n)
+    ns = (rng.standard_normal((n, state_dim)) * 2).astype(np.float32)
+    p0 = _flat(q.network)
+    w, b = orc.qnet_split(p0, state_dim, n_actions)
+    qv = q.q_values(torch.from_numpy(s).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(qv, orc.qnet_forward(w, b, s), rtol=0, atol=Q_TOL)
+    seat = torch.from_numpy(rng.integers(0, 3, n).astype(np.int32)).to(DEV)
+    acts = torch.full((n,), -3, dtype=torch.long, device=DEV)
+    q.epsilon = q.epsilon_end = 0.0
+    q.act_into(torch.from_numpy(s).to(DEV), seat, 1, acts, step_counter=4)
+    a = acts.cpu().numpy(); mine = seat.cpu().numpy() == 1
+    assert (a[~mine] == -3).all() and ((a[mine] >= 0) & (a[mine] < n_actions)).all()
+    top2 = np.sort(qv, axis=1)[:, -2:] if n_actions > 1 else None
+    clear = mine if n_actions == 1 else mine & ((top2[:, 1] - top2[:, 0]) > 4 * Q_TOL)
+    np.testing.assert_array_equal(a[clear], qv.argmax(axis=1)[clear])
+    act = rng.integers(0, n_actions, n).astype(np.int64); rew = rng.standard_normal(n).astype(np.float32); done = rng.random(n) < 0.4
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    rep = q.train_step_native(dev(s), dev(act), dev(rew), dev(ns), dev(done), None, step_counter=12).cpu().numpy()
+    grad, cnt, sq = orc.qnet_train_grads(p0, p0, s, act, rew, ns, done, None, 0.9, 0.1, 8, 12, 0)
+    tp, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    orc.qnet_adamw(p0, tp, grad, m, v, cnt, 1, 1e-3, 1e-4, update_freq=3)
+    assert rep[0] == cnt > 0
+    np.testing.assert_allclose(_flat(q.network), p0, rtol=0, atol=5e-5)        # 5 % of one learning-rate step (lr = 1e-3)
+
+
+def test_native_kernels_empty_and_full_selections(g):
+    q = _qnet(g, "s40", seed=1)
+    q.epsilon = q.epsilon_end = 0.0
+    n = 1000
+    s = torch.randn((n, 40), device=DEV)
+    acts = torch.full((n,), -1, dtype=torch.long, device=DEV)
+    q.act_into(s, torch.full((n,), 5, dtype=torch.int32, device=DEV), 2, acts)           # nobody's turn
+    assert (acts == -1).all()
+    q.act_into(s, torch.full((n,), 2, dtype=torch.int32, device=DEV), 2, acts)           # everybody's turn
+    np.testing.assert_array_equal(acts.cpu().numpy(), q.get_actions(s).cpu().numpy())
+    before = _flat(q.network)
+    rep = q.train_step_native(s[:0], acts[:0], torch.zeros(0, device=DEV), s[:0], torch.zeros(0, dtype=torch.bool, device=DEV))
+    assert np.array_equal(_flat(q.network), before)                                      # zero rows: nothing launched, nothing moves
