@@ -42,52 +42,55 @@ def episode_statistics(episodes_return) -> dict:
             "max": float(values.max()), "median": float(np.median(values))}
 
 
+def run_summary(env_name, episodes_return, start_time, end_time, total_steps, config) -> dict:
+    """The dictionary the reference dumps (utils/benchmarking/benchmarking.py:84-100), key for key."""
+    seconds = end_time - start_time
+    sps = round(float(total_steps / seconds), 4) if seconds > 0 else 0.0
+    return dict(env=env_name, config=config, start_time=start_time, end_time=end_time, total_training_seconds=seconds,
+                total_steps=total_steps, sps=sps, episode_stats=episode_statistics(episodes_return))
+
+
 class Benchmarker:
-    """utils/benchmarking/benchmarking.py:19-57"""
+    """Base of the run-summary writers; same constructor, switches and hook as utils/benchmarking/benchmarking.py:19-57."""
+    FEATURES = {"training_summary": True}
 
     def __init__(self, enabled: bool = True, feature_mask: Mapping[str, bool] | None = None,
                  results_dir_resolver: Callable[[str], Path] | None = None):
-        self.enabled = enabled
-        self.feature_mask = {"training_summary": True, **(feature_mask or {})}
-        self.results_dir_resolver = results_dir_resolver or result_folder_for
-
-    def is_enabled(self, feature_name: str) -> bool:
-        return self.enabled and self.feature_mask.get(feature_name, True)
+        self.enabled = bool(enabled)
+        self.feature_mask = dict(self.FEATURES)
+        self.feature_mask.update(feature_mask or {})
+        self.results_dir_resolver = result_folder_for if results_dir_resolver is None else results_dir_resolver
 
     @classmethod
     def from_config(cls, config: Mapping[str, object] | None = None) -> "Benchmarker":
-        config = config or {}
-        return cls(enabled=bool(config.get("enabled", True)), feature_mask=config.get("mask"))
+        cfg = dict(config or {})
+        return cls(enabled=bool(cfg.get("enabled", True)), feature_mask=cfg.get("mask"))
+
+    def is_enabled(self, feature_name: str) -> bool:
+        return self.enabled and bool(self.feature_mask.get(feature_name, True))
 
     def create_benchmark_file(self, env_name, episodes_return, start_time, end_time, total_steps, config):
         raise NotImplementedError
 
 
 class NullBenchmarker(Benchmarker):
-    def create_benchmark_file(self, env_name, episodes_return, start_time, end_time, total_steps, config):
+    """Writes nothing."""
+
+    def create_benchmark_file(self, *args, **kwargs):
         return None
 
 
 class YamlBenchmarker(Benchmarker):
+    """run_N.yaml under <results folder>/runs, N continuing the files already there."""
+
     def create_benchmark_file(self, env_name, episodes_return, start_time, end_time, total_steps, config):
         if not self.is_enabled("training_summary"):
             return None
-        path = next_run_path(self.results_dir_resolver(env_name))
-        seconds = end_time - start_time
-        summary = {
-            "env": env_name,
-            "config": config,
-            "start_time": start_time,
-            "end_time": end_time,
-            "total_training_seconds": seconds,
-            "total_steps": total_steps,
-            "sps": round(float(total_steps / seconds), 4) if seconds > 0 else 0.0,
-            "episode_stats": episode_statistics(episodes_return),
-        }
-        print(path)
-        with open(path, "w") as fh:
-            yaml.dump(summary, fh, default_flow_style=False)
-        return path
+        target = next_run_path(self.results_dir_resolver(env_name))
+        print(target)
+        target.write_text(yaml.dump(run_summary(env_name, episodes_return, start_time, end_time, total_steps, config),
+                                    default_flow_style=False))
+        return target
 
 
 def emit_llm_summary(report: dict) -> None:
