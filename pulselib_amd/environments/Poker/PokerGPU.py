@@ -96,6 +96,10 @@ class PokerGPU(_EnvBase):
         self.table_id0 = int(table_id0)
         self.episode = 0
         self.use_eval_cache = os.environ.get("PULSE_EVAL_CACHE", "1") != "0"
+        # opt-in: successive steps write their observation into two alternating buffers, so the tensor a step returned
+        # stays intact through the NEXT step (a trainer then needs no copy of the pre-step observation).  Off: the
+        # reference's single persistent buffer (PokerGPU.py:633).
+        self.double_buffer_obs = False
 
         self.raise_fractions = torch.tensor([0.25, 0.33, 0.50, 0.75, 1.00, 1.50, 2.00, 3.00, 4.00], device=device)
         self.obs_size = 13 + ((self.max_players - 1) * 3)
@@ -144,10 +148,12 @@ class PokerGPU(_EnvBase):
         self._pp = 0
         self._views = [None, None]
         self._types_cache = {}
+        object.__setattr__(self, "_obs_alt", None)
+        object.__setattr__(self, "_obs_bufs", None)
 
     def __setattr__(self, name, value):
         object.__setattr__(self, name, value)
-        if name in _TRACKED:
+        if name in _TRACKED or name == "double_buffer_obs":
             object.__setattr__(self, "_view_dirty", True)
 
     def set_agents(self, agents):
@@ -208,6 +214,13 @@ class PokerGPU(_EnvBase):
         if cur.data_ptr() == self._is_done_alt.data_ptr():
             object.__setattr__(self, "_is_done_alt", torch.zeros_like(cur))
         bufs = (cur, self._is_done_alt)
+        cur_obs = self._as_state("obs", torch.float32, (N, self.obs_size))
+        if self.double_buffer_obs:
+            if self._obs_alt is None or self._obs_alt.shape != cur_obs.shape or self._obs_alt.data_ptr() == cur_obs.data_ptr():
+                object.__setattr__(self, "_obs_alt", torch.zeros_like(cur_obs))
+            obs_bufs = (cur_obs, self._obs_alt)
+        else:
+            obs_bufs = (cur_obs, cur_obs)
         views = []
         for src, dst in ((0, 1), (1, 0)):
             v = _native.PokerView()
@@ -218,12 +231,14 @@ class PokerGPU(_EnvBase):
                 setattr(v, k, p)
             v.is_done = bufs[src].data_ptr()
             v.is_done_out = bufs[dst].data_ptr()
+            v.obs = obs_bufs[dst].data_ptr()
             views.append(v)
         inplace = _native.PokerView.from_buffer_copy(views[0])
         inplace.is_done_out = inplace.is_done
         object.__setattr__(self, "_views", views)
         object.__setattr__(self, "_view_inplace", inplace)
         object.__setattr__(self, "_done_bufs", bufs)
+        object.__setattr__(self, "_obs_bufs", obs_bufs)
         object.__setattr__(self, "_pp", 0)
         object.__setattr__(self, "_view_dirty", False)
 
@@ -233,6 +248,7 @@ class PokerGPU(_EnvBase):
         if inplace:
             v = self._view_inplace
             v.is_done = v.is_done_out = self.is_done.data_ptr()
+            v.obs = self._obs_bufs[self._pp].data_ptr()
             return v
         return self._views[self._pp]
 
@@ -307,6 +323,7 @@ class PokerGPU(_EnvBase):
         pp = 1 - self._pp
         object.__setattr__(self, "_pp", pp)
         object.__setattr__(self, "is_done", self._done_bufs[pp])
+        object.__setattr__(self, "obs", self._obs_bufs[pp])
         return self.obs, rewards, self.is_done, self.is_truncated, self.get_info()
 
     def policy_step(self, agent_types, actions, step_counter):
@@ -327,6 +344,7 @@ class PokerGPU(_EnvBase):
         pp = 1 - self._pp
         object.__setattr__(self, "_pp", pp)
         object.__setattr__(self, "is_done", self._done_bufs[pp])
+        object.__setattr__(self, "obs", self._obs_bufs[pp])
         return self.obs, rewards, self.is_done, self.is_truncated, self.get_info()
 
     def rollout(self, agent_types, actions, n_steps, step_counter0, time_every=0, stop_rule=None):
@@ -356,6 +374,7 @@ class PokerGPU(_EnvBase):
         new_pp = pp if n_steps % 2 == 0 else 1 - pp
         object.__setattr__(self, "_pp", new_pp)
         object.__setattr__(self, "is_done", self._done_bufs[new_pp])
+        object.__setattr__(self, "obs", self._obs_bufs[new_pp])
         return self.obs, self._rewards[last], self.is_done, self.is_truncated, self.get_info()
 
     # ------------------------------------------------------------------ white-box methods

@@ -71,6 +71,7 @@ class PokerQNetwork(nn.Module):
         # Philox keys of the exploration draws (act_into takes the env step counter; get_actions counts its calls)
         self.seed, self.table_id0 = int(seed), int(table_id0)
         self._calls = 0
+        self._struct_cache = {}
         self._lr_gate = None
         self.data_parallel = True            # under torch.distributed with > 1 rank: all-reduce the gradient every step
 
@@ -84,6 +85,11 @@ class PokerQNetwork(nn.Module):
 
     # ------------------------------------------------------------------ native action selection
     def _net_struct(self, net: nn.Sequential) -> _native.QNet:
+        # the parameters are views of the flat buffers for the life of the module (cuda): their addresses are cached
+        key = "target" if net is self.target_network else "net"
+        cached = self._struct_cache.get(key)
+        if cached is not None and cached[0] == net[LINEAR_INDICES[0]].weight.data_ptr():
+            return cached[1]
         s = _native.QNet()
         s.state_dim, s.n_actions = self.state_dim, self.action_dim
         for i, li in enumerate(LINEAR_INDICES, start=1):
@@ -94,6 +100,7 @@ class PokerQNetwork(nn.Module):
                                    "there is no CPU path")
             setattr(s, f"w{i}", w.data_ptr())
             setattr(s, f"b{i}", b.data_ptr())
+        self._struct_cache[key] = (net[LINEAR_INDICES[0]].weight.data_ptr(), s)
         return s
 
     @staticmethod
@@ -182,7 +189,12 @@ class PokerQNetwork(nn.Module):
                 "partials": torch.empty(TRAIN_BLOCKS * _native.lib().pulse_qnet_slice_floats(), dtype=torch.float32,
                                         device=dev),                                            # 37 MB at 256 workgroups
             }
-        t = _native.QNetTrain()
+        t = self._struct_cache.get("train")
+        if t is not None and t.params == self._flat.data_ptr():
+            t.lr, t.weight_decay, t.gamma, t.update_freq = self.lr, self.wd, float(self.gamma), int(self.update_freq)
+            t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
+            return t
+        t = self._struct_cache["train"] = _native.QNetTrain()
         t.net, t.target = self._net_struct(self.network), self._net_struct(self.target_network)
         t.params, t.target_params = self._flat.data_ptr(), self._flat_target.data_ptr()
         t.grad, t.exp_avg, t.exp_avg_sq = nat["grad"].data_ptr(), nat["m"].data_ptr(), nat["v"].data_ptr()

@@ -117,7 +117,12 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     host_rng = random.Random(host_seed)
     done_count = LaggedDoneCount(device, n_games, TERMINATION_THRESHOLD)
     actions = torch.zeros(n_games, dtype=torch.long, device=device)
-    state_before = torch.empty((n_games, env.obs_size), dtype=torch.float32, device=device)
+    # the env alternates two observation buffers from here on: the tensor a step returned is still intact while the
+    # next step runs, so the pre-step observation the learner needs is simply the previous `state` (no copy per step)
+    double_buffered = hasattr(env, "double_buffer_obs")
+    if double_buffered:
+        env.double_buffer_obs = True
+    state_before = None if double_buffered else torch.empty((n_games, env.obs_size), dtype=torch.float32, device=device)
     terminated = torch.zeros(n_games, dtype=torch.bool, device=device)
     active_games = torch.zeros(n_games, dtype=torch.bool, device=device)
     episode_reward = torch.zeros((), dtype=torch.float64, device=device)
@@ -139,7 +144,10 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         idx = 0
         while True:
             seat_idx = info["seat_idx"]
-            state_before.copy_(state)                                                 # the env reuses its obs buffer
+            if double_buffered:
+                state_before = state
+            else:
+                state_before.copy_(state)                                             # the env reuses its obs buffer
             if native:
                 # active_games = q_mask & ~terminated (trainGPU.py:85) comes out of the act launch; `terminated |= dones`
                 # (:86) and the episode reward (:96) ride on the training launches
@@ -181,6 +189,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         total_steps += n_games * idx                                                  # :108
 
     torch.cuda.synchronize(device)
+    if double_buffered:
+        env.double_buffer_obs = False
     end_time = time.time()
     elapsed = end_time - start_time
     summary = {"env": config.get("ENV_ID", "Pulse-Poker-GPU-v1"), "total_steps": total_steps, "start_time": start_time,

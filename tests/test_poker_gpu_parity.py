@@ -585,3 +585,35 @@ def test_stats_kernel_forms():
     both = torch.zeros(2, dtype=torch.float64, device=DEV)
     _native.check(lib.pulse_poker_stats(d.data_ptr(), r.data_ptr(), None, n, None, both.data_ptr(), st), "stats")
     assert float(both[1]) == float(done.sum()) and abs(float(both[0]) - float(rew.astype(np.float64).sum())) < 1e-6
+
+
+def test_double_buffered_observations_keep_the_previous_step_intact():
+    """double_buffer_obs: same observations as the single persistent buffer, step for step, and the tensor returned by a
+    step (or reset) is not touched by the NEXT step -- what the fused trainer relies on instead of copying."""
+    N = 4096
+    plain = _gpu_env(n_players=6, max_players=10, n_games=N, seed=4)
+    dbl = _gpu_env(n_players=6, max_players=10, n_games=N, seed=4)
+    dbl.double_buffer_obs = True
+    rng = np.random.default_rng(9)
+    for ep in range(2):
+        o1, _ = plain.reset(options={"active_players": 6 - ep, "rotation": ep})
+        o2, _ = dbl.reset(options={"active_players": 6 - ep, "rotation": ep})
+        np.testing.assert_array_equal(to_np(o2), to_np(o1))
+        prev, prev_copy = o2, to_np(o2).copy()
+        for s in range(12):
+            a = torch.from_numpy(rng.integers(0, 13, N)).to(DEV)
+            if s % 3 == 2:                                   # also through the fused policy step and the native roll-out
+                types = [1] * 6
+                o1 = plain.policy_step(types, a.clone(), 50 + s)[0]
+                o2 = dbl.rollout(types, a.clone(), 1, 50 + s)[0]
+            else:
+                o1 = plain.step(a)[0]
+                o2 = dbl.step(a)[0]
+            np.testing.assert_array_equal(to_np(o2), to_np(o1), err_msg=f"episode {ep} step {s}")
+            np.testing.assert_array_equal(to_np(prev), prev_copy, err_msg="the previous observation was overwritten")
+            assert o2.data_ptr() != prev.data_ptr() and dbl.obs.data_ptr() == o2.data_ptr()
+            prev, prev_copy = o2, to_np(o2).copy()
+        assert_state_equal(_snap(dbl), _snap(plain), ctx=f"episode {ep}")
+    dbl.double_buffer_obs = False
+    o = dbl.step(torch.zeros(N, dtype=torch.long, device=DEV))[0]
+    assert dbl.step(torch.zeros(N, dtype=torch.long, device=DEV))[0].data_ptr() == o.data_ptr()      # back to one buffer
