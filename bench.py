@@ -4,28 +4,40 @@
 Workload (BASELINE.json configs[1], config/pokerGPU.yaml of the reference): 65,536 parallel tables per
 GPU, 10 seats (the 9 scripted opponents of pokerGPU.yaml:5-14 + the Q seat, played by `random` in this
 env-only measurement), STARTING_BBS 100, W1 .5, W2 .3, K 100, ALPHA 50; decks shuffled on device
-(reference: rand().argsort() per reset, PokerGPU.py:86); `active_players` sampled 2..10 per episode
-(PokerGPU.py:76-80) from a host RNG seeded 0; seat rotation per episode as scripts/Poker/trainGPU.py:58-72;
-episode stop rule of trainGPU.py:27-33 (every 5th step, >80 % of tables done), evaluated without a host
-sync one 5-step chunk late (--stop-rule sync gives the reference's blocking check).
+(reference: rand().argsort() per reset, PokerGPU.py:86) with Philox keyed by (seed 20260401, global table id,
+episode); `active_players` sampled 2..10 per episode (PokerGPU.py:76-80) from a host RNG seeded 0; seat rotation
+per episode as scripts/Poker/trainGPU.py:58-72; episode stop rule of trainGPU.py:27-33 (every 5th step, >80 % of
+ALL the job's tables done), evaluated without a host sync exactly one 5-step chunk late (--stop-rule sync gives
+the reference's blocking check).
 
-One "step" = one pass of the hot path over the batch = scripted-opponent policy + PokerGPU.step, ONE fused
-HIP launch (pulse_poker_policy_step).  Steps are counted like the reference: n_tables x step calls,
-finished tables included (trainGPU.py:108).  Resets run inside the timed region and are not counted.
+One "step" = one pass of the hot path over the batch = scripted-opponent policy + PokerGPU.step for every table.
+Steps are counted like the reference: n_tables x step calls, finished tables included (trainGPU.py:108).  Resets run
+inside the timed region and are not counted.  The roll-out enqueues a 5-step chunk as ONE launch
+(pulse_poker_rollout: state in registers across the steps, every step's observation / reward / done / action stored).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the fused step kernel: algorithmic bytes per launch
-(453 B per table-step) over the kernel's mean duration from HIP event pairs recorded
-on the launch stream around every 8th 5-launch chunk of the timed region (kernel boundaries included; bracketing every
-chunk cost 10 % of the throughput it was measuring).  `cpu_baseline` times the oracle
-(oracle/poker_oracle.c, the CPU restatement of the same policy+step) on the host cores, rank 0 at N=1 only.
+`--steps K --warmup W`: W untimed steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides and max-reduced over the ranks.  A 20-step block is ~0.1 ms, so the block is repeated (`config.repeats`) until
+the blocks sum to >= 50 ms and span >= 8 episodes; `ms_per_step` / `value` come from the MEDIAN block, the mean and
+the spread are in `config.blocks`.
+
+Launching: `python bench.py --gpus N` spawns N rank processes itself (this parent never touches the GPU);
+under torchrun (WORLD_SIZE set) the process is a rank.  Rank 0 prints ONE JSON line.  `roofline` prices the chunk
+kernel: algorithmic bytes per launch (453 B per table-step x tables x steps in the launch) over
+its mean duration from HIP event pairs recorded on the launch stream around every 4th launch of the timed blocks.
+`cpu_baseline` (N = 1 only) times the oracle (oracle/poker_oracle.c, the CPU restatement of the same policy + step +
+reset + shuffle, same seeds => the same games) in a short-lived child process of its own, so that no OpenMP pool ever
+lives in a process that holds the GPU.  `trainer_loop` (N = 1 only) is the second line SURVEY.md 8d asks for: the same
+environment with the learner (PokerQNetwork) acting and training every step.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import random
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,33 +46,37 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-import torch  # noqa: E402
-
 AGENTS = ["tight_aggressive", "heuristic_hands", "heuristic_hands", "loose_passive", "tight_aggressive",
           "random", "loose_passive", "small_ball", "tight_aggressive"]   # reference config/pokerGPU.yaml:5-14
 BYTES_PER_TABLE_STEP = 453          # 173 + 28*P at P = 10
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CHECK_INTERVAL = 5                  # trainGPU.py:31
 TERMINATION_THRESHOLD = 0.8         # trainGPU.py:76
+SEED = 20260401
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU (weak scaling)")
     ap.add_argument("--stop-rule", choices=["lagged", "sync"], default="lagged")
-    ap.add_argument("--launcher", choices=["native", "python"], default="native",
-                    help="native: 5-step chunks enqueued by pulse_poker_rollout; python: one ctypes call per step")
     ap.add_argument("--max-episode-steps", type=int, default=40,
                     help="episode cap: the reference's close-on-aggressor rule livelocks tables whose last ACTIVE seat "
                          "keeps calling against all-ins (SURVEY.md A.3), so >20 %% of tables may never finish; its "
                          "published runs average 31-35 steps per episode (results/PokerGPU/runs/run_2..8.yaml)")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="repeat the K-step block until the blocks sum to this")
+    ap.add_argument("--min-episodes", type=int, default=8, help="... and span at least this many episodes")
+    ap.add_argument("--max-repeats", type=int, default=4000)
+    ap.add_argument("--per-step-launches", action="store_true", help="one launch per step instead of one per chunk (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inproc", action="store_true", help="measure in this process (no guard child); see guarded()")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--trainer-loop", choices=["auto", "on", "off"], default="auto", help="auto: at N = 1")
+    ap.add_argument("--trainer-episodes", type=int, default=12)
+    ap.add_argument("--role", choices=["launcher", "rank", "cpu"], default="launcher", help=argparse.SUPPRESS)
+    ap.add_argument("--inproc", action="store_true", help="measure in this process (what a profiler wraps); same as --role rank")
+    return ap.parse_args(argv)
 
 
 def native_types_for_episode(episode: int):
@@ -74,105 +90,125 @@ def native_types_for_episode(episode: int):
     return native, q_seat, rotation
 
 
-class Runner:
-    """Episode loop of scripts/Poker/trainGPU.py:57-108 without the learner."""
+def _log(msg):
+    """Progress marks on stderr (stdout carries only the JSON line): a silent bench cannot be told from a hung one."""
+    print(f"[bench {time.strftime('%H:%M:%S')} pid {os.getpid()}] {msg}", file=sys.stderr, flush=True)
 
-    def __init__(self, args, rank, world, device):
-        from pulselib_amd.environments.Poker import PokerGPU
-        self.args, self.rank, self.world, self.device = args, rank, world, device
-        self.N = args.tables
-        self.env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=self.N, starting_bbs=100,
-                            max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=20260401, table_id0=rank * self.N)
-        self.actions = torch.zeros(self.N, dtype=torch.long, device=device)
-        self.host_rng = random.Random(0)
+
+# ------------------------------------------------------------------------------------------------ episode loop
+class EpisodeLoop:
+    """Episode logic of scripts/Poker/trainGPU.py:57-108 without the learner, over chunks of CHECK_INTERVAL steps.
+    `env` needs reset(options) and rollout(types, actions, n, step0, timer=, stop_rule=); `rule` is a
+    stoprule.LaggedDoneCount (or anything with over() / drain()); `on_episode_end` runs at every boundary (the
+    per-episode statistics all-reduce).  Every rank of a job makes the same sequence of calls: the stop verdicts come
+    from the job-wide count at a fixed lag, everything else is a function of (episode, host RNG seed)."""
+
+    def __init__(self, env, rule, actions, max_episode_steps, on_episode_end=None, host_seed=0, n_players=10):
+        self.env, self.rule, self.actions = env, rule, actions
+        self.max_episode_steps, self.on_episode_end = max_episode_steps, on_episode_end
+        self.host_rng = random.Random(host_seed)
+        self.n_players = n_players
         self.episode = 0
         self.global_step = 0           # Philox offset of the scripted policies
         self.steps_in_episode = 0
-        from pulselib_amd.stoprule import LaggedDoneCount
-        self.done_count = LaggedDoneCount(device, self.N, TERMINATION_THRESHOLD)
-        self.episode_stats = torch.zeros(2, dtype=torch.float64, device=device)          # all-reduced copy (cumulative over episodes)
-        self.episode_stats_local = torch.zeros(2, dtype=torch.float64, device=device)
+        self.calls = 0
         self.new_episode()
 
     def new_episode(self):
         self.native, q_seat, rotation = native_types_for_episode(self.episode)
-        A = self.host_rng.randint(2, 10)                       # PokerGPU.py:77 (host RNG: no .item() sync)
+        A = self.host_rng.randint(2, self.n_players)                  # PokerGPU.py:77 (host RNG: no .item() sync)
         self.env.reset(options={"rotation": rotation, "active_players": int(A), "q_agent_seat": q_seat})
         self.episode += 1
         self.steps_in_episode = 0
-        self.done_count.drain()
+        self.rule.drain()
 
-    def run_steps(self, k, time_every=0):
+    def run_steps(self, k, timer=None, time_every=0):
         """Run exactly k counted steps (episodes roll over inside)."""
         done = 0
-        env = self.env
         while done < k:
-            n = min(CHECK_INTERVAL, k - done)
-            if self.args.launcher == "native":      # the chunk's launches and its done-count in one native call
-                env.rollout(self.native, self.actions, n, self.global_step, time_every=time_every, stop_rule=self.done_count)
-            else:
-                for i in range(n):
-                    env.policy_step(self.native, self.actions, self.global_step + i)
-                self.done_count.submit(env.is_done)
+            n = min(CHECK_INTERVAL, k - done, self.max_episode_steps - self.steps_in_episode)
+            tm = timer if (timer is not None and time_every > 0 and self.calls % time_every == 0) else None
+            self.env.rollout(self.native, self.actions, n, self.global_step, timer=tm, stop_rule=self.rule)
+            self.calls += 1
             self.global_step += n
             self.steps_in_episode += n
             done += n
             # trainGPU.py:99: the check happens at idx % 5 == 0, i.e. after steps 1, 6, 11, ...; chunks of five
             # steps check after steps 5, 10, ... -- same cadence, first check four steps later.
-            if self.done_count.over(blocking=self.args.stop_rule == "sync") or self.steps_in_episode >= self.args.max_episode_steps:
-                self.end_episode()
+            if self.rule.over() or self.steps_in_episode >= self.max_episode_steps:
+                if self.on_episode_end is not None:
+                    self.on_episode_end(self)
+                self.new_episode()
         return done
 
-    def end_episode(self):
+
+class EpisodeStatsReducer:
+    """The only cross-GPU exchange of the data path besides the stop rule's count: per-episode statistics
+    (RCCL all-reduce over xGMI of two doubles, asynchronous).  Accumulates {sum of the last step's rewards, tables done}."""
+
+    def __init__(self, env, device, world):
+        import torch
+        self.env, self.device, self.world = env, device, world
+        self.local = torch.zeros(2, dtype=torch.float64, device=device)      # cumulative over episodes
+        self.reduced = torch.zeros(2, dtype=torch.float64, device=device)
+        self.work = None
+        self.collectives = 0
+
+    def __call__(self, loop):
+        import torch
+        env = self.env
+        env._lib.pulse_poker_stats(env.is_done.data_ptr(), env._rewards[0].data_ptr(), None, env.n_games, None,
+                                   self.local.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
         if self.world > 1:
             import torch.distributed as dist
-            # the only cross-GPU exchange of the path: episode statistics (RCCL all-reduce over xGMI)
-            if getattr(self, "_stats_work", None) is not None:
-                self._stats_work.wait()              # stream-ordered for RCCL: the buffer is about to be rewritten
-                self._stats_work = None
-            # one launch: {sum of the last step's rewards, tables done} added into a cumulative double[2]
-            env = self.env
-            env._lib.pulse_poker_stats(env.is_done.data_ptr(), env._rewards[0].data_ptr(), None, self.N, None,
-                                       self.episode_stats_local.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
-            if dist.get_backend() == "gloo":      # one-GPU rehearsal: gloo reduces host copies
-                host = self.episode_stats_local.cpu()
+            if self.work is not None:
+                self.work.wait()                     # stream-ordered for RCCL: the buffer is about to be rewritten
+            if dist.get_backend() == "gloo":         # one-GPU rehearsal: gloo reduces host copies
+                host = self.local.cpu()
                 dist.all_reduce(host)
+                self.reduced.copy_(host)
             else:
-                self.episode_stats.copy_(self.episode_stats_local)
-                self._stats_work = dist.all_reduce(self.episode_stats, async_op=True)
-        self.new_episode()
+                self.reduced.copy_(self.local)
+                self.work = dist.all_reduce(self.reduced, async_op=True)
+            self.collectives += 1
+
+    def totals(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        t = (self.reduced if self.world > 1 else self.local).cpu().tolist()
+        return {"last_step_reward_sum": t[0], "tables_done_at_episode_end": t[1], "episode_collectives": self.collectives}
 
 
-def cpu_baseline(args, n_tables):
-    """Oracle (CPU restatement) timed on the host cores over a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (child)
+def cpu_baseline(args):
+    """Oracle (CPU restatement) timed on the host cores over a bounded sample of the same workload: same seeds, same
+    Philox decks, same scripted-opponent draws, same `active_players` sequence and rotation as the GPU leg."""
     import numpy as np
     from oracle import oracle as orc
-    threads = os.cpu_count() or 1
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    threads = int(os.environ.get("PULSE_CPU_THREADS", min(threads, 16)))   # the 1-GPU box's CPU share is 16 cores
+    n_tables = args.tables
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     env = orc.OraclePokerEnv(n_players=10, max_players=10, n_games=n_tables, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
                              K=100, alpha=50, n_threads=threads)
-    rng = np.random.default_rng(0)
     host_rng = random.Random(0)
     actions = np.zeros(n_tables, dtype=np.int64)
-    # decks: the oracle takes injected decks; build one seeded set outside the timed region and reuse it
-    decks = np.argsort(rng.random((n_tables, 52)), axis=1).astype(np.int32) + 1
     total_steps, elapsed, episode, gstep = 0, 0.0, 0, 0
     while elapsed < args.cpu_seconds and episode < 5000:
         native, q_seat, rotation = native_types_for_episode(episode)
         A = host_rng.randint(2, 10)
         t0 = time.perf_counter()
+        decks = orc.shuffle_decks(SEED, 0, episode, n_tables)        # what the reset kernel draws for (seed, table, episode)
         env.reset(options={"rotation": rotation, "active_players": A, "q_agent_seat": q_seat, "prefixed_decks": decks})
-        idx = 0
+        idx, verdicts = 0, []
         while True:
-            env.policy_step(native, 20260401, gstep, actions)
+            env.policy_step(native, SEED, gstep, actions)
             gstep += 1
             idx += 1
-            if idx % CHECK_INTERVAL == 0 and env.is_done.mean() > TERMINATION_THRESHOLD:
-                break
+            if idx % CHECK_INTERVAL == 0:
+                verdicts.append(env.is_done.mean() > TERMINATION_THRESHOLD)
+                lag = 0 if args.stop_rule == "sync" else 1
+                if len(verdicts) > lag and verdicts[-1 - lag]:          # the GPU leg's fixed-lag rule
+                    break
             if idx >= args.max_episode_steps:
                 break
         elapsed += time.perf_counter() - t0
@@ -180,38 +216,68 @@ def cpu_baseline(args, n_tables):
         episode += 1
     return {"value": total_steps / elapsed, "unit": "env-steps/sec", "cores": threads, "kind": "port",
             "sample": f"{episode} episodes x {n_tables} tables, {total_steps} table-steps in {elapsed:.1f} s "
-                      f"(oracle/poker_oracle.c policy+step, OpenMP over tables, stop rule as trainGPU.py:27-33, "
+                      f"(oracle/poker_oracle.c shuffle+reset+policy+step, OpenMP over tables, same seeds / decks / draws / "
+                      f"active_players sequence as the GPU leg, stop rule as trainGPU.py:27-33 one check late, "
                       f"cap {args.max_episode_steps} steps/episode)"}
 
 
-def recorded_traffic(tables):
-    """HBM-side bytes per launch of the fused step kernel from the newest committed rocprofv3 PMC summary
+# ------------------------------------------------------------------------------------------------ trainer loop leg
+def trainer_loop_leg(args, device):
+    """The second line of SURVEY.md 8d: the reference trainer's loop (scripts/Poker/trainGPU.py:57-108) -- the learner
+    acting and training every step -- on the native path (scripts/trainGPU.py: train_agent_fused)."""
+    import torch
+    from pulselib_amd.environments.Poker import PokerAgentType, PokerGPU, PokerQNetwork, load_gpu_agents
+    from pulselib_amd.scripts.trainGPU import train_agent_fused
+    agents, types = load_gpu_agents(device, 9, AGENTS, 100, 13)
+    torch.manual_seed(SEED)
+    q = PokerQNetwork(None, device, gamma=.95, update_freq=20, state_dim=40, action_dim=13, learning_rate=2e-4, weight_decay=1e-5,
+                      seed=SEED)
+    agents.insert(0, q)
+    types.insert(0, PokerAgentType.QLEARNING)
+    env = PokerGPU(device=device, agents=agents, n_players=10, max_players=10, n_games=args.tables, starting_bbs=100, max_bbs=1000,
+                   w1=.5, w2=.3, K=100, alpha=50, seed=SEED)
+    kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=False)
+    train_agent_fused(env, agents, types, 2, args.tables, device, **kw)          # warm-up episodes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = train_agent_fused(env, agents, types, args.trainer_episodes, args.tables, device, **kw)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    steps = out["total_steps"] // args.tables
+    return {"value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "ms_per_step": elapsed / max(steps, 1) * 1e3,
+            "tables": args.tables, "episodes": args.trainer_episodes, "steps": steps,
+            "learner": "PokerQNetwork 40-128-128-64-32-13, fp32 MFMA kernels (act, train, reduce, AdamW), acting and training every step",
+            "counts_as": "n_games x steps incl. finished tables (trainGPU.py:108), episodes timed end to end incl. resets and the per-episode read-back",
+            "reference_published": {"value": 2.5e7, "tables": 2000000, "hardware": "unnamed CUDA GPU",
+                                    "source": "results/PokerGPU/runs/run_2.yaml:35 (BASELINE.md section 1)"}}
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def recorded_traffic(tables, steps_per_launch):
+    """HBM-side bytes per launch of the chunk kernel from the newest committed rocprofv3 PMC summary
     (profiles/rNN/step_kernel_profile.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected by the
     dword-stream calibration recorded with them).  None if no summary matches this workload."""
     best = None
     for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile.json")):
         try:
             d = json.loads(f.read_text())
-            if int(d.get("tables_per_launch", -1)) == tables:
+            if int(d.get("tables_per_launch", -1)) == tables and int(d.get("steps_per_launch", 1)) == steps_per_launch:
                 best = float(d["traffic_bytes_per_launch"])
         except Exception:
             pass
     return best
 
 
-def _log(msg):
-    """Progress marks on stderr (stdout carries only the JSON line): a silent bench cannot be told from a hung one."""
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-
-def main():
+def main_rank(args):
     import faulthandler
     # a bench that takes minutes is a bug: dump every thread's stack and exit instead of hanging the box
     faulthandler.dump_traceback_later(int(os.environ.get("PULSE_BENCH_WATCHDOG_S", "360")), exit=True)
-    args = parse_args()
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # rehearsal knob for a one-GPU box: PULSE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 with the gloo
@@ -221,6 +287,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -230,106 +297,216 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
+        if dist is not None:
             dist.barrier()
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        _log("cpu_baseline (oracle port) ...")
-        cpu = cpu_baseline(args, args.tables)
-        _log(f"cpu_baseline done: {cpu['value']:.3g} steps/s on {cpu['cores']} cores")
-
-    runner = Runner(args, rank, world, device)
-    lib = runner.env._lib
-    if rank == 0:
-        _log(f"environment ready ({args.tables} tables/GPU x {world}); warm-up {args.warmup} steps ...")
-    runner.run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if rank == 0:
-        _log(f"timing {args.steps} steps ...")
-    s_ms, n_t = C.c_float(0), C.c_int32(0)
-    lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))     # drop warm-up samples
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # HIP events around every 8th five-launch chunk of the timed region (>= 75 chunks sampled at the default 3,000 steps)
-    ran = runner.run_steps(args.steps, time_every=8 if args.launcher == "native" else 0)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert ran == args.steps
-    if rank == 0:
-        _log(f"timed region done: {elapsed * 1e3:.1f} ms")
-
-    lib.pulse_rollout_timing_collect(C.byref(s_ms), C.byref(n_t))
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    from pulselib_amd.environments.Poker import PokerGPU
+    from pulselib_amd.stoprule import LaggedDoneCount, RolloutTimer
+    N = args.tables
+    env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100,
+                   max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=SEED, table_id0=rank * N)
+    env.chunked_rollout = not args.per_step_launches
+    rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world)
+    stats = EpisodeStatsReducer(env, device, world)
+    actions = torch.zeros(N, dtype=torch.long, device=device)
+    loop = EpisodeLoop(env, rule, actions, args.max_episode_steps, on_episode_end=stats)
+    timer = RolloutTimer()
+    if rank == 0:
+        _log(f"environment ready ({N} tables/GPU x {world}, stop-rule exchange: {rule.exchange}); warm-up {args.warmup} steps ...")
+    loop.run_steps(args.warmup)
+    torch.cuda.synchronize()
+    timer.collect()
+    if rank == 0:
+        _log(f"timing blocks of {args.steps} steps ...")
+
+    blocks, episodes0 = [], loop.episode
+    while True:
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ran = loop.run_steps(args.steps, timer=timer, time_every=4)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        assert ran == args.steps
+        blocks.append(max_over_ranks(dt))               # identical on every rank: so is the decision below
+        enough = sum(blocks) * 1e3 >= args.min_timed_ms and loop.episode - episodes0 >= args.min_episodes
+        if enough or len(blocks) >= args.max_repeats:
+            break
+    sum_ms, n_launches, n_steps_timed = timer.collect()
+    episodes_timed = loop.episode - episodes0
+    if rank == 0:
+        _log(f"timed region done: {len(blocks)} blocks, {sum(blocks) * 1e3:.1f} ms")
+
+    trainer = None
+    if args.trainer_loop == "on" or (args.trainer_loop == "auto" and world == 1):
+        if rank == 0:
+            _log("trainer-loop leg ...")
+        del loop, env
+        trainer = trainer_loop_leg(args, device)
+        if rank == 0:
+            _log(f"trainer loop: {trainer['value']:.3g} env-steps/s")
 
     if rank == 0:
-        total_tables = args.tables * world
-        value = total_tables * args.steps / elapsed
+        med = statistics.median(blocks)
+        total_tables = N * world
         roofline = None
-        if n_t.value > 0:
-            kernel_s = (s_ms.value / n_t.value) * 1e-3
-            achieved = BYTES_PER_TABLE_STEP * args.tables / kernel_s / 1e9
+        if n_launches > 0:
+            kernel_s = sum_ms * 1e-3 / n_launches
+            steps_per_launch = n_steps_timed / n_launches
+            alg = BYTES_PER_TABLE_STEP * N * steps_per_launch
+            achieved = alg / kernel_s / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": recorded_traffic(args.tables), "kernel": "poker_step_kernel<PH_STEP, POLICY>", "kernel_us": kernel_s * 1e6,
-                        "launches_timed": n_t.value, "algorithmic_bytes_per_launch": BYTES_PER_TABLE_STEP * args.tables}
+                        "traffic": recorded_traffic(N, int(round(steps_per_launch))),
+                        "kernel": "poker_step_kernel<PH_STEP, POLICY, MULTI>" if not args.per_step_launches else "poker_step_kernel<PH_STEP, POLICY>",
+                        "kernel_us": kernel_s * 1e6, "launches_timed": n_launches, "steps_per_launch": steps_per_launch,
+                        "algorithmic_bytes_per_launch": alg,
+                        "note": "algorithmic bytes = 453 B per table-step (SURVEY.md 8d) x tables x steps the launch processes; "
+                                "a chunk re-reads no state between its steps, so HBM traffic per launch is below this figure"}
         out = {
-            "metric": "env-steps/sec (whole node), Poker batched tables", "value": value, "unit": "env-steps/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "env-steps/sec (whole node), Poker batched tables", "value": total_tables * args.steps / med, "unit": "env-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": med / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"Poker {args.tables} tables/GPU x {world} GPU, 10 seats, config/pokerGPU.yaml opponents, "
-                                   f"env-only (policy+step fused), device-shuffled decks, active_players 2..10",
-                       "tables_per_gpu": args.tables, "n_players": 10, "stop_rule": args.stop_rule, "max_episode_steps": args.max_episode_steps, "launcher": args.launcher,
-                       "episodes": runner.episode, "parallelism": f"tables sharded x{world}, no data-path collective"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": f"Poker {N} tables/GPU x {world} GPU, 10 seats, config/pokerGPU.yaml opponents, "
+                                   f"env-only (policy+step fused, 5-step chunks), device-shuffled decks, active_players 2..10",
+                       "tables_per_gpu": N, "n_players": 10, "stop_rule": args.stop_rule, "stop_rule_exchange": rule.exchange,
+                       "max_episode_steps": args.max_episode_steps, "steps_per_launch": CHECK_INTERVAL if not args.per_step_launches else 1,
+                       "repeats": len(blocks), "episodes_timed": episodes_timed,
+                       "blocks": {"median_ms": med * 1e3, "mean_ms": statistics.fmean(blocks) * 1e3, "min_ms": min(blocks) * 1e3,
+                                  "max_ms": max(blocks) * 1e3, "sum_ms": sum(blocks) * 1e3,
+                                  "value_from_mean": total_tables * args.steps / statistics.fmean(blocks)},
+                       "episode_stats": stats.totals(),
+                       "parallelism": f"tables sharded x{world}, no data-path collective; stop-rule count + episode statistics all-reduced"},
+            "roofline": roofline, "trainer_loop": trainer,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    else:
+        stats.totals()
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def guarded():
-    """Single-GPU default: run the measurement in a child process (this one never touches the GPU) so that a
-    run that wedges -- seen twice on fresh boxes, cause unknown, never in a re-run -- is killed and repeated once
-    instead of costing the round its number.  `--inproc` (or torchrun ranks, or PULSE_BENCH_INPROC=1) measures in
-    this process; profilers wrap that form (tools/collect_profiles.sh)."""
-    import subprocess
-    limit = int(os.environ.get("PULSE_BENCH_ATTEMPT_S", "300"))
-    env = dict(os.environ, PULSE_BENCH_WATCHDOG_S=str(max(30, limit - 20)))
-    for attempt in (1, 2):
-        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--inproc"],
-                                 stdout=subprocess.PIPE, text=True, env=env)
-        try:
-            out, _ = child.communicate(timeout=limit)
-        except subprocess.TimeoutExpired:
-            _log(f"attempt {attempt}: no result after {limit} s, killing pid {child.pid}")
-            child.kill()
-            try:
-                child.communicate(timeout=20)
-            except subprocess.TimeoutExpired:
-                pass
+# ------------------------------------------------------------------------------------------------ launcher (parent)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _passthrough_args(argv):
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
             continue
+        if a == "--role":
+            skip = True
+            continue
+        if a.startswith("--role=") or a == "--inproc":
+            continue
+        out.append(a)
+    return out
+
+
+def run_cpu_child(args, argv):
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = int(os.environ.get("PULSE_CPU_THREADS", min(threads, 16)))       # the 1-GPU box's CPU share is 16 cores
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    _log(f"cpu_baseline (oracle port, {threads} threads) in a child process ...")
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), *_passthrough_args(argv), "--role", "cpu"],
+                           stdout=subprocess.PIPE, text=True, env=env, timeout=args.cpu_seconds * 6 + 120)
+    except subprocess.TimeoutExpired:
+        _log("cpu_baseline child timed out")
+        return None
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        _log(f"cpu_baseline child failed (exit {p.returncode})")
+        return None
+    cpu = json.loads(lines[-1])
+    _log(f"cpu_baseline done: {cpu['value']:.3g} steps/s on {cpu['cores']} cores")
+    return cpu
+
+
+def launcher(args, argv):
+    """This process never touches the GPU: it runs the CPU baseline in one child, then N rank children
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each), and prints rank 0's JSON line.  A rank set that
+    produces no line within the limit is killed, its stderr (with the watchdog's stack dump) is kept under
+    gpurun_out/bench_wedge_<time>.log, and the measurement is repeated ONCE; the line says so (`attempts`)."""
+    cpu = None
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = run_cpu_child(args, argv)
+    limit = int(os.environ.get("PULSE_BENCH_ATTEMPT_S", "420"))
+    base = _passthrough_args(argv)
+    for attempt in (1, 2):
+        port = _free_port()
+        procs, errs = [], []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), PULSE_BENCH_WATCHDOG_S=str(max(30, limit - 30)))
+            err = open(f"/tmp/pulse_bench_{os.getpid()}_a{attempt}_r{r}.err", "w+")
+            errs.append(err)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *base, "--role", "rank"],
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err, text=True, env=env))
+        out, timed_out = "", False
+        try:
+            out, _ = procs[0].communicate(timeout=limit)
+            for p in procs[1:]:
+                p.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    pass
+        logs = []
+        for r, err in enumerate(errs):
+            err.seek(0)
+            logs.append(f"==== rank {r} (exit {procs[r].returncode}) ====\n{err.read()}")
+            err.close()
+            os.unlink(err.name)
+        sys.stderr.write("\n".join(logs) + "\n")
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-        if child.returncode == 0 and lines:
-            print(lines[-1], flush=True)
+        ok = not timed_out and all(p.returncode == 0 for p in procs) and lines
+        if ok:
+            line = json.loads(lines[-1])
+            line["cpu_baseline"] = cpu
+            line["attempts"] = attempt
+            print(json.dumps(line), flush=True)
             return 0
-        _log(f"attempt {attempt}: exit code {child.returncode}")
-        sys.stdout.write(out)
-        if child.returncode == 2:                    # argparse: repeating will not help
+        wedge = ROOT / "gpurun_out" / f"bench_wedge_{time.strftime('%Y%m%d_%H%M%S')}_a{attempt}.log"
+        try:
+            wedge.parent.mkdir(exist_ok=True)
+            wedge.write_text(f"attempt {attempt}: timed_out={timed_out}, exits={[p.returncode for p in procs]}\n" + "\n".join(logs) + "\nstdout:\n" + out)
+            _log(f"attempt {attempt} failed (timed out: {timed_out}); record kept in {wedge}")
+        except OSError:
+            _log(f"attempt {attempt} failed (timed out: {timed_out})")
+        if any(p.returncode == 2 for p in procs):                    # argparse / usage error: repeating will not help
             return 2
     return 1
 
 
 if __name__ == "__main__":
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--inproc" in sys.argv or os.environ.get("PULSE_BENCH_INPROC") == "1":
-        main()
+    _args = parse_args()
+    if _args.role == "cpu":
+        print(json.dumps(cpu_baseline(_args)), flush=True)
+    elif _args.role == "rank" or _args.inproc or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PULSE_BENCH_INPROC") == "1":
+        main_rank(_args)
     else:
-        sys.exit(guarded())
+        sys.exit(launcher(_args, sys.argv[1:]))

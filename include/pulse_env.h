@@ -59,9 +59,13 @@ enum {
  * is_done_out may alias is_done (in-place) or be a second buffer (the host code ping-pongs two so
  * that the tensor returned by step() is not rewritten by the next step, as in PokerGPU.py:619-623).
  */
+/* flags: kernel variants a caller (or a test) selects per view; 0 = the product defaults */
+#define PULSE_VIEW_NO_OBS_STAGING 0x1  /* store the observation column by column instead of LDS-staged 16-byte bursts  */
+#define PULSE_VIEW_NO_CHUNK       0x2  /* pulse_poker_rollout: one launch per step instead of one launch per chunk     */
 typedef struct PulsePokerView {
-    int32_t n_games, n_players, active_players, max_players;
+    int32_t n_games, n_players, active_players, max_players;   /* n_games <= 2^24 per view (shard larger batches) */
     int32_t obs_size, hand_ranks_len;
+    int32_t flags, reserved0;
     const int32_t* hand_ranks;
     int32_t *pots, *stages, *deck_positions, *button, *sb, *bb, *idx, *highest, *agg, *acted,
             *last_raise_size, *prev_stacks, *prev_invested;
@@ -142,7 +146,9 @@ int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, voi
  * obs device fp32[n,obs_stride] (columns 5,6 = hole cards, 9 = pot), seat_idx device int32[n] (the
  * `curr_players` argument).  For every table whose seat has a scripted type, actions[t] is written;
  * EXTERNAL seats are left untouched.  agent_types: host uint8[n_players] (PULSE_AGENT_*).
- * Random draws: Philox4x32-10(seed, table id + table_id0, step_counter). */
+ * Random draws (the scripted-opponent stream): call = Philox4x32-10(seed, table id + table_id0, step_counter >> 1);
+ * an even step_counter takes words (x, y) of the call, an odd one (z, w) -- x/z feed the action's randint, y/w
+ * loose_passive's rand() (Player.py:146).  One call serves two steps: the chunked roll-out draws eight steps in one pass. */
 int pulse_poker_policy(const float* obs, int32_t obs_stride, const int32_t* seat_idx, int32_t n,
                        const uint8_t* agent_types, int32_t n_players, uint64_t seed, uint64_t step_counter,
                        uint64_t table_id0, int64_t* actions, void* stream);
@@ -152,32 +158,53 @@ int pulse_poker_policy(const float* obs, int32_t obs_stride, const int32_t* seat
 int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
                             uint64_t table_id0, int64_t* actions, float* rewards, void* stream);
 
-/* Roll-out: n_steps fused policy+step launches enqueued back to back from native code (no host work
- * between launches).  v_even/v_odd are the two ping-pong views (is_done <-> is_done_out swapped);
- * step i uses v_even / rewards_even when i is even.  Philox offset of step i = step_counter0 + i.
- * time_every > 0: every time_every-th call brackets its chunk of n_steps launches with ONE HIP event pair on
- * `stream`; read the summed time and the number of launches it covers with pulse_rollout_timing_collect() AFTER
- * synchronising the stream (mean per launch = sum / launches, kernel boundaries included). */
+/* Roll-out: n_steps fused policy+step transitions enqueued by ONE native call and, by default, executed by ONE
+ * launch: every table's state is loaded once, stepped n_steps times in registers and its changed words stored once,
+ * while every step still stores its observation, reward, done flag and action -- step i into the even buffers
+ * (v_even->obs, v_even->is_done_out, rewards_even) when i is even, else into the odd ones (v_odd->obs,
+ * v_odd->is_done_out, rewards_odd).  Memory after the call is bit-identical to calling pulse_poker_policy_step
+ * n_steps times on v_even, v_odd, v_even, ... (PULSE_VIEW_NO_CHUNK in v_even->flags does exactly that instead).
+ * v_odd must be v_even with is_done <-> is_done_out swapped (obs may differ: double-buffered observations).
+ * Draws of step i: the scripted-opponent stream at step_counter0 + i (pulse_poker_policy).
+ * timer (NULL or a pulse_timer_create handle): the call is bracketed by one HIP event pair on `stream`; read the
+ * summed time, the launches and the steps covered with pulse_timer_collect() AFTER synchronising the stream.
+ * stoprule (NULL or a pulse_stoprule_create handle): the tables done after the last step are counted for it by the
+ * launch itself (each wavefront stores its count; no extra kernel on `stream`). */
 int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
-                        float* rewards_even, float* rewards_odd, int32_t n_steps, int32_t time_every, void* stoprule,
+                        float* rewards_even, float* rewards_odd, int32_t n_steps, void* timer, void* stoprule,
                         void* stream);
-/* `stoprule` (NULL or a pulse_stoprule_create handle): the done tables of the last state are counted for it -- by the
- * last launch itself (each wavefront stores its count; no extra kernel), equivalent to pulse_stoprule_submit on the
- * final done flags.
- *
- * The trainer's episode stop rule (scripts/Poker/trainGPU.py:27-33: every 5th step, > threshold of the tables done)
- * without its blocking read: submit counts the done flags in stream order and copies the count to pinned host memory
- * on a side stream; over() answers from the counts that have ALREADY arrived (blocking != 0: waits for all submitted
- * ones -- the reference's behaviour); drain() consumes what is in flight (episode boundary).  This handle is the one
- * piece of state the library keeps: a side stream, four events, 16 bytes of device and of pinned host memory,
- * created on the current device. */
-int pulse_stoprule_create(int32_t n_tables, double threshold, void** handle);
-int pulse_stoprule_submit(void* handle, const uint8_t* is_done, void* stream);
-int pulse_stoprule_over(void* handle, int32_t blocking, int32_t* over);
+int pulse_timer_create(void** timer);
+int pulse_timer_collect(void* timer, float* sum_ms, int32_t* n_launches, int64_t* n_steps);
+int pulse_timer_destroy(void* timer);
+
+/* The trainer's episode stop rule (scripts/Poker/trainGPU.py:27-33,99: every 5th step, more than `threshold` of the
+ * tables done ends the episode) without its blocking read, for one GPU or for one process per GPU.
+ * A "chunk" is one check point.  submit (or pulse_poker_rollout) counts the chunk's done tables in stream order; on
+ * the handle's side stream the count is summed, all-reduced over the ranks when a communicator is attached (RCCL:
+ * 8 bytes, off the step stream), and copied to pinned host memory.  decide() answers for the chunk submitted `lag`
+ * chunks before the newest one -- a FIXED lag, so a run is reproducible and every rank of a job takes every
+ * decision on the same chunk and ends every episode at the same step (equal collective sequences on all ranks).
+ * lag 0 is the reference's blocking check; lag 1 (default of the host code) never waits in practice.
+ * counts() returns the same chunk's local and global count (have = 0: no chunk of this episode is due yet); a host
+ * that owns the cross-rank exchange itself (gloo) all-reduces `local`.  drain() marks an episode boundary: earlier
+ * chunks decide nothing any more.  n_global = tables of the whole job (= n_local without a communicator).
+ * The handle owns a side stream, 8 events, and < 1 MB of device / pinned memory, created on the current device. */
+int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, int32_t lag, void* comm, void** handle);
+int pulse_stoprule_submit(void* handle, const uint8_t* flags, int32_t n, void* stream);   /* flags: device uint8[n], != 0 = done */
+int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t* have);
+int pulse_stoprule_decide(void* handle, int32_t* over);
 int pulse_stoprule_drain(void* handle);
 int pulse_stoprule_destroy(void* handle);
-int pulse_rollout_timing_collect(float* sum_ms, int32_t* n_timed);
+
+/* RCCL communicator of the job (one process per GPU), used for the stop rule's 8-byte all-reduce on its side
+ * stream.  librccl is bound at run time (the copy PyTorch-ROCm loaded, else the system one), so the library loads
+ * without it.  unique_id: call on rank 0, hand the 128 bytes to every rank (torch.distributed broadcast), then
+ * every rank calls create (collective).  all_reduce_i64: sum of int64[count], device pointers, in `stream` order. */
+int pulse_comm_unique_id(uint8_t* out128);
+int pulse_comm_create(const uint8_t* id128, int32_t rank, int32_t world, void** comm);
+int pulse_comm_all_reduce_i64(void* comm, const int64_t* send, int64_t* recv, int32_t count, void* stream);
+int pulse_comm_destroy(void* comm);
 
 /* Diagnostic only (tools/ablate_step.py): fused policy+step with phases compiled out, to price them. */
 int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* actions, float* rewards, uint64_t types_packed,

@@ -433,6 +433,7 @@ void oracle_philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset, uint32_t
 void oracle_shuffle_decks(uint64_t seed, uint64_t table_id0, uint64_t episode, int key_bits, int n_tables,
                           int32_t* decks) {
     const int shift = (key_bits > 0 && key_bits < 32) ? 32 - key_bits : 0;
+    #pragma omp parallel for schedule(static)               /* tables are independent; bench.py's CPU leg shuffles 65,536 per episode */
     for (int t = 0; t < n_tables; t++) {
         uint32_t key[52]; int32_t* d = decks + (size_t)t * 52;
         for (int s = 0; s < 13; s++) {
@@ -451,7 +452,8 @@ void oracle_shuffle_decks(uint64_t seed, uint64_t table_id0, uint64_t episode, i
 
 static int rand_below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)n) >> 32); }
 
-int oracle_scripted_action(int type, int c1, int c2, int pot, const uint32_t rnd[4]) {
+/* rnd[0] feeds the action's randint, rnd[1] loose_passive's rand() (Player.py:146); see oracle_policy_draw */
+int oracle_scripted_action(int type, int c1, int c2, int pot, const uint32_t rnd[2]) {
     const int r1 = pymod(c1, 13), r2 = pymod(c2, 13);
     const int d = r1 > r2 ? r1 - r2 : r2 - r1;
     const int pair = r1 == r2;
@@ -481,6 +483,17 @@ int oracle_scripted_action(int type, int c1, int c2, int pot, const uint32_t rnd
     return a;
 }
 
+/* The scripted opponents' draw for (table, step) -- the definition the HIP kernels are held to: one Philox call
+ * serves two consecutive steps, call = Philox4x32-10(seed, table id, step >> 1); an even step takes words (x, y) of
+ * the call, an odd step (z, w).  (torch's generator stream of the reference cannot be reproduced in a kernel; only
+ * the distributions are the reference's, Player.py:99,121,146 / utils.py:121.) */
+void oracle_policy_draw(uint64_t seed, uint64_t table_id, uint64_t step_counter, uint32_t out[2]) {
+    uint32_t call[4];
+    oracle_philox4x32(seed, table_id, step_counter >> 1, call);
+    out[0] = (step_counter & 1) ? call[2] : call[0];
+    out[1] = (step_counter & 1) ? call[3] : call[1];
+}
+
 /* build_actions over the batch from the observation buffer (utils.py:108-123) */
 void oracle_policy(const OraclePoker* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
                    uint64_t table_id0, int64_t* actions, int n_threads) {
@@ -490,8 +503,8 @@ void oracle_policy(const OraclePoker* v, const uint8_t* agent_types, uint64_t se
         const int type = agent_types[v->idx[t] & 15];
         if (!type) continue;
         const float* o = v->obs + (size_t)t * v->obs_size;
-        uint32_t rnd[4];
-        oracle_philox4x32(seed, table_id0 + (uint64_t)t, step_counter, rnd);
+        uint32_t rnd[2];
+        oracle_policy_draw(seed, table_id0 + (uint64_t)t, step_counter, rnd);
         actions[t] = oracle_scripted_action(type, (int)o[5], (int)o[6], (int)o[9], rnd);
     }
 }

@@ -23,6 +23,9 @@ PH_CAPTURE, PH_EQUITY, PH_EXECUTE, PH_ADVANCE = 0x001, 0x002, 0x004, 0x008
 PH_FOLDWIN, PH_SHOWDOWN, PH_CLEARDONE, PH_REWARD, PH_OBS = 0x010, 0x020, 0x040, 0x080, 0x100
 PH_STEP = 0x1FF
 
+# PulsePokerView.flags: kernel variants selectable per view (include/pulse_env.h)
+VIEW_NO_OBS_STAGING, VIEW_NO_CHUNK = 0x1, 0x2
+
 AGENT_EXTERNAL, AGENT_RANDOM, AGENT_HEURISTIC_HANDS, AGENT_TIGHT_AGGRESSIVE, AGENT_LOOSE_PASSIVE, AGENT_SMALL_BALL = range(6)
 
 
@@ -32,7 +35,8 @@ class PulseError(RuntimeError):
 
 class PokerView(C.Structure):
     _fields_ = (
-        [(n, C.c_int32) for n in ("n_games", "n_players", "active_players", "max_players", "obs_size", "hand_ranks_len")]
+        [(n, C.c_int32) for n in ("n_games", "n_players", "active_players", "max_players", "obs_size", "hand_ranks_len",
+                                  "flags", "reserved0")]
         + [(n, C.c_void_p) for n in (
             "hand_ranks",
             "pots", "stages", "deck_positions", "button", "sb", "bb", "idx", "highest", "agg", "acted",
@@ -87,13 +91,20 @@ SYMBOLS = {
     "pulse_poker_reset": (C.c_int, [_P, _P, _P]),
     "pulse_poker_policy": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _U64, _U64, _U64, _P, _P]),
     "pulse_poker_policy_step": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, _P]),
-    "pulse_poker_rollout": (C.c_int, [_P, _P, _P, _U64, _U64, _U64, _P, _P, _P, _I32, _I32, _P, _P]),
-    "pulse_stoprule_create": (C.c_int, [_I32, C.c_double, _P]),
-    "pulse_stoprule_submit": (C.c_int, [_P, _P, _P]),
-    "pulse_stoprule_over": (C.c_int, [_P, _I32, _P]),
+    "pulse_poker_rollout": (C.c_int, [_P, _P, _P, _U64, _U64, _U64, _P, _P, _P, _I32, _P, _P, _P]),
+    "pulse_timer_create": (C.c_int, [_P]),
+    "pulse_timer_collect": (C.c_int, [_P, _P, _P, _P]),
+    "pulse_timer_destroy": (C.c_int, [_P]),
+    "pulse_stoprule_create": (C.c_int, [_I32, _I64, C.c_double, _I32, _P, _P]),
+    "pulse_stoprule_submit": (C.c_int, [_P, _P, _I32, _P]),
+    "pulse_stoprule_counts": (C.c_int, [_P, _P, _P, _P]),
+    "pulse_stoprule_decide": (C.c_int, [_P, _P]),
     "pulse_stoprule_drain": (C.c_int, [_P]),
     "pulse_stoprule_destroy": (C.c_int, [_P]),
-    "pulse_rollout_timing_collect": (C.c_int, [_P, _P]),
+    "pulse_comm_unique_id": (C.c_int, [_P]),
+    "pulse_comm_create": (C.c_int, [_P, _I32, _I32, _P]),
+    "pulse_comm_all_reduce_i64": (C.c_int, [_P, _P, _P, _I32, _P]),
+    "pulse_comm_destroy": (C.c_int, [_P]),
     "pulse_poker_ablate": (C.c_int, [_P, _U32, _P, _P, _U64, _U64, _P]),
     "pulse_calib_stream": (C.c_int, [_P, _U64, _I32, _P]),
     "pulse_poker_stats": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
@@ -119,7 +130,7 @@ def build(force: bool = False) -> Path:
     """Compile libpulse_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = list(_CSRC.glob("*.hip")) + list(_CSRC.glob("*.cpp")) + list(_CSRC.glob("*.h")) + [_PKG.parent / "include" / "pulse_env.h"]
     if force or not _SO.exists() or any(s.stat().st_mtime > _SO.stat().st_mtime for s in srcs):
-        subprocess.check_call(["make", "-C", str(_CSRC)] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", str(_CSRC), f"-j{min(8, os.cpu_count() or 1)}"] + (["-B"] if force else []))
     return _SO
 
 

@@ -1,0 +1,188 @@
+// poker_device.h -- device helpers shared by the hold'em kernels (poker_step.hip, poker.hip).
+// Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+
+#include "pulse_internal.h"
+
+namespace pulse_dev {
+
+constexpr int kBlock = 256;   // 4 wavefronts per workgroup in every kernel of the path
+
+__device__ __forceinline__ int pymod(int x, int m) { int r = x % m; return r < 0 ? r + m : r; }
+
+// ---------------------------------------------------------------- hand-rank walk
+__device__ __forceinline__ int hr_at(const int32_t* __restrict__ hr, uint32_t len, int i) {
+    return (uint32_t)i < len ? hr[(uint32_t)i] : 0;
+}
+// same value, but the load is unconditional (index clamped to slot 0, result masked): independent lookups
+// written back to back stay back to back in the instruction stream instead of becoming branches
+__device__ __forceinline__ int hr_at_nb(const int32_t* __restrict__ hr, uint32_t len, int i) {
+    const bool ok = (uint32_t)i < len;
+    const int x = hr[ok ? (uint32_t)i : 0u];
+    return ok ? x : 0;
+}
+// seven dependent gathers: p = HR[p + c_i], p0 = 53 (PokerGPU.py:437-444).  A card of 0 re-reads
+// slot 0 of the state, which is exactly the extra HR[p] / HR[HR[p]] lookups of the turn / flop
+// equities (PokerGPU.py:500, :521), so all three streets share one 7-step chain.
+__device__ __forceinline__ int walk7(const int32_t* __restrict__ hr, uint32_t len, int c0, int c1, int c2, int c3,
+                                     int c4, int c5, int c6) {
+    int p = 53;
+    p = hr_at(hr, len, p + c0); p = hr_at(hr, len, p + c1); p = hr_at(hr, len, p + c2);
+    p = hr_at(hr, len, p + c3); p = hr_at(hr, len, p + c4); p = hr_at(hr, len, p + c5);
+    p = hr_at(hr, len, p + c6);
+    return p;
+}
+
+// ---------------------------------------------------------------- evaluation cache tags
+// pre_board: five 6-bit cards (the board this episode will deal) | valid bit 30.
+// pre_hands: two 6-bit hole cards | valid bit 12.  A cached value is used only when the cards found
+// in state at that moment are in 1..52 and equal the cached ones, so it is the value the reference's
+// literal chain would produce (the table state after a set of distinct cards does not depend on order).
+constexpr uint32_t kPreBoardValid = 1u << 30, kPreHandsValid = 1u << 12;
+__device__ __forceinline__ bool card_ok(int c) { return (uint32_t)(c - 1) < 52u; }
+__device__ __forceinline__ uint32_t pack_board(int b0, int b1, int b2, int b3, int b4) {
+    return (uint32_t)(b0 & 63) | (uint32_t)(b1 & 63) << 6 | (uint32_t)(b2 & 63) << 12 | (uint32_t)(b3 & 63) << 18 | (uint32_t)(b4 & 63) << 24;
+}
+__device__ __forceinline__ uint32_t pack_hand(int h0, int h1) { return (uint32_t)(h0 & 63) | (uint32_t)(h1 & 63) << 6 | kPreHandsValid; }
+// n_cards of the current board (3, 4 or 5) are dealt, valid and equal to the cached ones
+__device__ __forceinline__ bool board_matches(uint32_t tag, int n_cards, int b0, int b1, int b2, int b3, int b4) {
+    const uint32_t mask = (1u << (6 * n_cards)) - 1u;
+    const bool in_range = card_ok(b0) && card_ok(b1) && card_ok(b2) && (n_cards < 4 || card_ok(b3)) && (n_cards < 5 || card_ok(b4));
+    return (tag & kPreBoardValid) && in_range && ((pack_board(b0, b1, b2, b3, b4) ^ tag) & mask) == 0;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset) {
+    uint32_t c0 = (uint32_t)offset, c1 = (uint32_t)(offset >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        // one 32x32 -> 64 multiply per word pair (v_mad_u64_u32): 32-bit integer multiplies are the slow VALU ops here
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ int rand_below(uint32_t r, int n) { return (int)__umulhi(r, (uint32_t)n); }
+__device__ __forceinline__ float rand_unit(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// The scripted opponents' draw for (table, step): one Philox call serves two consecutive steps --
+// call = Philox4x32-10(seed, table id, step >> 1); an even step takes words (x, y), an odd step (z, w).
+// `pick` feeds the randint of the action, `coin` loose_passive's rand() (Player.py:146).
+struct PolicyDraw { uint32_t pick, coin; };
+__device__ __forceinline__ PolicyDraw policy_draw(const U4& call, uint64_t step) {
+    // mask arithmetic, not `odd ? z : x`: the compiler turns that select into an indexed read of the call,
+    // which then lives in scratch memory
+    const uint32_t m = 0u - (uint32_t)(step & 1u);
+    PolicyDraw d;
+    d.pick = (call.x & ~m) | (call.z & m);
+    d.coin = (call.y & ~m) | (call.w & m);
+    return d;
+}
+
+// ---------------------------------------------------------------- scripted opponents
+// environments/Poker/Player.py:79-176 + utils.py:121; c1,c2 = hole cards 1..52, pot = obs col 9.
+__device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot, const PolicyDraw& rnd) {
+    const int r1 = pymod(c1, 13), r2 = pymod(c2, 13);
+    const int d = r1 > r2 ? r1 - r2 : r2 - r1;
+    const bool pair = r1 == r2;
+    int a = 0;
+    switch (type) {
+    case PULSE_AGENT_RANDOM:                                              // utils.py:121
+        a = rand_below(rnd.pick, 13); break;
+    case PULSE_AGENT_HEURISTIC_HANDS: {                                   // Player.py:85-102
+        const bool fold = r1 < 8 && r2 < 8;
+        const bool raise = (pair || r1 >= 10 || r2 >= 10) && !fold;
+        a = raise ? 2 + rand_below(rnd.pick, 9) : 0; break; }
+    case PULSE_AGENT_TIGHT_AGGRESSIVE: {                                  // Player.py:112-124
+        const bool fold = r1 < 7 && r2 < 7 && d > 5;
+        const bool raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
+        a = fold ? 0 : 1;
+        if (raise) a = 2 + 5 + rand_below(rnd.pick, 4);
+        break; }
+    case PULSE_AGENT_LOOSE_PASSIVE: {                                     // Player.py:134-149
+        const bool fold = r1 <= 4 && r2 <= 4 && d > 9;
+        const bool call = ((pair && r1 > 8) || (r1 >= 11 && r2 > 9) || (r2 >= 11 && r1 > 9)) && !fold;
+        const bool raise = rand_unit(rnd.coin) > 0.9f && call;
+        a = call ? 1 : 0;
+        if (raise) a = 2 + rand_below(rnd.pick, 4);
+        break; }
+    case PULSE_AGENT_SMALL_BALL: {                                        // Player.py:159-174
+        const bool fold = (r1 < 6 && r2 < 6 && pot > 30) || (r1 < 9 && r2 < 9 && pot > 80);
+        const bool raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
+        a = raise ? 2 + rand_below(rnd.pick, 3) : 0; break; }
+    default: break;
+    }
+    return a;
+}
+
+// 32-bit byte-offset addressing: base pointers are wave-uniform (SGPR pair) and every array of a view is
+// far below 4 GiB, so an access is `global_load v, v_off, s[base]` with no 64-bit VALU address arithmetic.
+template <class T> __device__ __forceinline__ T ldo(const T* __restrict__ base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T> __device__ __forceinline__ void sto(T* __restrict__ base, uint32_t byte_off, T val) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = val;
+}
+
+// ---------------------------------------------------------------- DPP cross-lane steps (no LDS traffic)
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;                               // quad_perm:[1,0,3,2] / [2,3,0,1]
+constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0x128;
+
+// reductions over the 4 lanes of a quad (two quad-permute steps) and over a 16-lane DPP row (four rotations)
+#define PULSE_REDUCE(NAME, TYPE, OP)                                                                  \
+    __device__ __forceinline__ TYPE quad_##NAME(TYPE v) {                                              \
+        TYPE o = (TYPE)dpp_mov<kQuadXor1>((int)v); v = OP(v, o);                                       \
+        o = (TYPE)dpp_mov<kQuadXor2>((int)v); v = OP(v, o);                                            \
+        return v;                                                                                      \
+    }                                                                                                  \
+    __device__ __forceinline__ TYPE row_##NAME(TYPE v) {                                               \
+        TYPE o = (TYPE)dpp_mov<kRowRor1>((int)v); v = OP(v, o);                                        \
+        o = (TYPE)dpp_mov<kRowRor2>((int)v); v = OP(v, o);                                             \
+        o = (TYPE)dpp_mov<kRowRor4>((int)v); v = OP(v, o);                                             \
+        o = (TYPE)dpp_mov<kRowRor8>((int)v); v = OP(v, o);                                             \
+        return v;                                                                                      \
+    }
+#define PULSE_OP_OR(a, b) ((a) | (b))
+#define PULSE_OP_MIN(a, b) min((a), (b))
+#define PULSE_OP_MAX(a, b) max((a), (b))
+#define PULSE_OP_ADD(a, b) ((a) + (b))
+PULSE_REDUCE(or, uint32_t, PULSE_OP_OR)
+PULSE_REDUCE(imin, int, PULSE_OP_MIN)
+PULSE_REDUCE(imax, int, PULSE_OP_MAX)
+PULSE_REDUCE(sum, int, PULSE_OP_ADD)
+#undef PULSE_REDUCE
+
+// x mod A for x that is almost always within one period of [0, A): two conditional corrections,
+// integer division only on the (poked-state) slow path.
+__device__ __forceinline__ int mod_near(int x, int A) {
+    if ((uint32_t)(x + A) < (uint32_t)(3 * A)) { x += x < 0 ? A : 0; x -= x >= A ? A : 0; return x; }
+    return pymod(x, A);
+}
+// first seat (x+1 .. x+A) % A whose bit is set in `bits` (bits limited to seats < A); -1 if none.
+__device__ __forceinline__ int first_after_near(uint32_t bits, int x, int A) {
+    const int xm = mod_near(x, A);
+    const uint32_t maskA = (1u << A) - 1u;
+    const uint32_t rot = ((bits >> (xm + 1)) | (bits << (A - 1 - xm))) & maskA;   // bit k <-> seat (xm+1+k)%A
+    if (!rot) return -1;
+    const int seat = xm + 1 + (__ffs((int)rot) - 1);
+    return seat >= A ? seat - A : seat;
+}
+
+}  // namespace pulse_dev
+
+// host-side helpers shared by the translation units
+namespace pulse {
+int check_view(const PulsePokerView* v, const char* who);
+int finish_launch(const char* what);
+uint64_t pack_types(const uint8_t* agent_types, int n_players);
+}  // namespace pulse

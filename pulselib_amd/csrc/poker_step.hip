@@ -1,0 +1,739 @@
+// poker_step.hip -- the fused hold'em step for gfx950: one launch per PokerGPU.step, or ONE launch for a whole
+// chunk of roll-out steps with the tables' state held in registers in between.
+//
+// Replaces the ~1,700 eager torch dispatches of one PokerGPU.step (environments/Poker/PokerGPU.py:527-633).
+//
+// Mapping: a table is owned by 4 adjacent lanes (one DPP quad), lane j owns seats j, j+4, j+8 (, j+12): 16 tables
+// per 64-wide wavefront, 64 per 256-thread workgroup.  Per-table scalars are replicated in the quad, so the scalar
+// part of the state machine costs 1/4 wave-instruction per table; per-seat rows ([N,P] int32, the reference's own
+// layout) are SPL unrolled dwords per lane.  Seat sets (ACTIVE seats, contenders, winners) are bitmasks OR-reduced
+// across the quad with DPP quad_perm modifiers (no LDS); "first ACTIVE seat after x" is a rotate + ffs on the mask;
+// side-pot layers are quad min/max butterflies.  All integer arithmetic is the reference's; the fp32 reward keeps
+// torch's op order (no contraction; tanh rounded once from double).
+//
+// Memory: single step -- state is read once and only the words that changed are written back, in the reference's
+// own SoA tensors, so the drop-in class exposes them unchanged.  Chunk (pulse_poker_rollout) -- state is read once
+// per chunk, every step still stores its observation / reward / done flag / action (ping-pong buffers, exactly what
+// n single launches leave behind), and the changed state words are written once at the end.  The 130 MB hand-rank
+// table is only touched when a poked state misses the evaluation cache the reset kernel fills.
+#include "poker_device.h"
+
+using namespace pulse_dev;
+
+namespace {
+
+constexpr int LPT = 4;        // lanes per table (one DPP quad)
+
+struct PolicyArgs {
+    uint64_t types_packed, seed, step_counter, table_id0;
+    uint32_t* wave_done;                   // nullptr, or one word per wavefront of the launch: tables done after the last step
+};
+struct ChunkArgs {                         // MULTI only: the odd steps' output buffers and the number of steps
+    float* obs_odd;
+    float* rewards_odd;
+    int n_steps;
+};
+
+// In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
+// in the product): lane 0 of every wavefront stores s_memtime at phase boundaries into a buffer of its own.
+#ifndef PULSE_STAMPS
+#define PULSE_STAMPS 0
+#endif
+#if PULSE_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP(i) do { if ((threadIdx.x & 63) == 0 && g_stamp_buf) { __builtin_amdgcn_sched_barrier(0); \
+    g_stamp_buf[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// tanh rounded once from double: 1 - 2/(exp(2x)+1) (abs. error ~1e-16, far below the fp32 ulp)
+__device__ __forceinline__ float tanh_rn(float x) {
+    const double e2 = exp(2.0 * (double)x);
+    return (float)(1.0 - 2.0 / (e2 + 1.0));
+}
+
+// WOBS (n_games % 16 == 0): the observation rows of a wavefront's 16 tables are one contiguous
+// 16 x obs_size x 4 B block in HBM.  Written column by column they cost thirteen store instructions that each
+// touch sixteen cache lines; with WOBS the lanes drop their values into the wavefront's LDS slice and the
+// block leaves as three 1-KiB bursts (16 B per lane).  A wavefront's LDS operations retire in order, so no
+// workgroup barrier is involved.
+// MULTI: ca.n_steps steps in one launch (fused policy only); step i writes observation / done flag / reward into
+// the even (i even) or odd buffers, as n single launches on the two ping-pong views would.
+template <uint32_t PH, bool POLICY, int SPL, bool WOBS, bool MULTI>
+__global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
+                                                           const int32_t* __restrict__ actor_idx_in,
+                                                           float* __restrict__ rewards, const PolicyArgs pa, const ChunkArgs ca) {
+    static_assert(SPL == 3 || SPL == 4, "seats per lane: 3 (<= 12 seats) or 4 (<= 16)");
+    static_assert(!MULTI || (POLICY && PH == PULSE_PH_STEP), "a chunk is fused policy + full step");
+    extern __shared__ int4 smem4[];
+    const int gt = blockIdx.x * kBlock + threadIdx.x;
+    const int t = gt / LPT;
+    const int j = gt % LPT;
+    if (t >= v.n_games) return;   // whole quads leave together
+    STAMP(0);
+    const int P = v.n_players, A = v.active_players;
+    const int32_t* __restrict__ hr = v.hand_ranks;
+    const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
+
+    // ---- load (every load is independent: all in flight at once).  n_games <= 2^24 (check_view): 24-bit multiplies.
+    const uint32_t ut = (uint32_t)t, so = ut * 4u, bo = ut * 20u;      // byte offsets into [N] int32 / board
+    int idx = ldo(v.idx, so), button = ldo(v.button, so), pot = ldo(v.pots, so), stage = ldo(v.stages, so), dpos = ldo(v.deck_positions, so);
+    int highest = ldo(v.highest, so), agg = ldo(v.agg, so), acted = ldo(v.acted, so), lrs = ldo(v.last_raise_size, so);
+    bool done = ldo(v.is_done, ut) != 0;
+    bool dirty = ldo(v.equity_dirty, ut) != 0;
+    int b0 = ldo(v.board, bo), b1 = ldo(v.board, bo + 4), b2 = ldo(v.board, bo + 8), b3 = ldo(v.board, bo + 12), b4 = ldo(v.board, bo + 16);
+    int stack[SPL], bet[SPL], inv[SPL], status[SPL], h0[SPL], h1[SPL];
+    float eq[SPL];
+    const uint32_t row0 = __umul24(ut, (uint32_t)P), eq0 = __umul24(ut, (uint32_t)A);
+#define ROW_OFF(k) ((row0 + (uint32_t)(j + LPT * (k))) * 4u)          /* byte offset of (table, seat) in an [N,P] int32 array */
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int seat = j + LPT * k;
+        stack[k] = 0; bet[k] = 0; inv[k] = 0; status[k] = PULSE_SITOUT; h0[k] = -1; h1[k] = -1; eq[k] = 0.5f;
+        if (seat < P) {
+            stack[k] = ldo(v.stacks, ROW_OFF(k)); bet[k] = ldo(v.current_round_bet, ROW_OFF(k));
+            inv[k] = ldo(v.total_invested, ROW_OFF(k)); status[k] = ldo(v.status, ROW_OFF(k));
+            if (!MULTI) {          // a chunk reads hole cards where it needs them (they never change inside an episode)
+                const int2 h = ldo(reinterpret_cast<const int2*>(v.hands), ROW_OFF(k) * 2u);
+                h0[k] = h.x; h1[k] = h.y;
+            }
+        }
+        if (seat < A) eq[k] = ldo(v.equities, (eq0 + (uint32_t)seat) * 4u);
+    }
+    // hole cards of one seat / of this lane's seat k, from memory (chunk) or from the registers loaded above
+    auto hand_of_seat = [&](int seat) -> int2 {        // seat in 0..15: what SEAT_PICK(h0/h1, seat) yields
+        if (seat < P) return ldo(reinterpret_cast<const int2*>(v.hands), (row0 + (uint32_t)seat) * 8u);
+        return seat < LPT * SPL ? make_int2(-1, -1) : make_int2(0, 0);
+    };
+    long long act64 = 0;
+    if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = ldo(actions, ut * 8u);
+    // the Philox draws depend on no load: issue them now, they execute under the load latency.  In a chunk lane j
+    // of the quad computes call (first + j): four calls = eight steps of draws in the time of one.
+    const uint64_t tid = pa.table_id0 + (uint64_t)t;
+    uint64_t pool_base = pa.step_counter >> 1;
+    U4 pool{0, 0, 0, 0};
+    if (POLICY) pool = philox4x32(pa.seed, tid, pool_base + (MULTI ? (uint64_t)j : 0u));
+    const float w1 = *v.w1, w2 = *v.w2;
+    const int Kdiv = *v.K, alpha = *v.alpha;
+    uint32_t pre_tag = 0;
+    if ((PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board) pre_tag = (uint32_t)ldo(v.pre_board, so);
+
+    // What the launch changes is written back once, after the last step; only changed records are stored (a table's
+    // seat rows change in one or two cells per step; writing everything back doubles the store traffic).  A flag is
+    // raised wherever a group of words is assigned: bit k of cells_dirty = this lane's seat k (its four row cells),
+    // bet_dirty = {pot, highest, agg, acted, last_raise_size, idx}, street_dirty = {stage, deck position, dirty flag},
+    // board_dirty = the five board cards.
+    uint32_t cells_dirty = 0;
+    bool bet_dirty = false, street_dirty = false, board_dirty = false;
+    int prev_stack = 0, prev_invested = 0;
+
+    // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
+#define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return quad_or(m_); }())
+#define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)quad_or(r_); }())
+
+    STAMP(1);   // loads issued
+    // The seat to act, as every lane of the table sees it: status / stack / round bet / hole cards.  Nothing changes
+    // between the observation a step writes (for the NEXT seat to act) and the following step's capture, so a chunk
+    // carries these five values from one step to the next instead of picking them twice.
+    int a_status = 0, a_stack = 0, a_bet = 0, a_h0 = 0, a_h1 = 0;
+    if (MULTI) {
+        const int seat0 = idx & 15;
+        a_status = SEAT_PICK(status, seat0); a_stack = SEAT_PICK(stack, seat0); a_bet = SEAT_PICK(bet, seat0);
+        const int2 h = hand_of_seat(seat0);
+        a_h0 = h.x; a_h1 = h.y;
+    }
+    const int n_steps = MULTI ? ca.n_steps : 1;
+    for (int i = 0; i < n_steps; ++i) {
+        const bool odd = MULTI && (i & 1);
+        float* __restrict__ const obs_dst = odd ? ca.obs_odd : v.obs;
+        uint8_t* __restrict__ const done_dst = odd ? v.is_done : v.is_done_out;
+        float* __restrict__ const rew_dst = odd ? ca.rewards_odd : rewards;
+
+        // ---- capture (PokerGPU.py:530-539)
+        const bool prev_done = done;
+        const int actor = ((PH & PULSE_PH_CAPTURE) || !actor_idx_in ? idx : actor_idx_in[t]) & 15;
+        if (!MULTI) {
+            a_status = SEAT_PICK(status, actor); a_stack = SEAT_PICK(stack, actor); a_bet = SEAT_PICK(bet, actor);
+            if (POLICY) { a_h0 = SEAT_PICK(h0, idx & 15); a_h1 = SEAT_PICK(h1, idx & 15); }
+        }
+        const bool has_legal_actor = a_status != PULSE_FOLDED && a_status != PULSE_ALLIN && a_status != PULSE_SITOUT && !prev_done;
+        prev_invested = a_bet;
+        if (!(PH & PULSE_PH_CAPTURE)) prev_invested = ldo(v.prev_invested, so);
+        prev_stack = a_stack;
+
+        STAMP(2);   // first loads have arrived (actor values picked)
+        // ---- scripted opponents (environments/Poker/utils.py:108-123), fused in front of the step
+        if (POLICY) {
+            const uint64_t step = pa.step_counter + (uint64_t)i;
+            PolicyDraw draw;
+            if (MULTI) {
+                const uint64_t call = step >> 1;
+                if (call - pool_base >= (uint64_t)LPT) {              // wave-uniform: the pool of four calls is used up
+                    pool_base = call;
+                    pool = philox4x32(pa.seed, tid, call + (uint64_t)j);
+                }
+                const int rel = (int)(call - pool_base);
+                const PolicyDraw mine = policy_draw(pool, step);
+                draw.pick = quad_or(j == rel ? mine.pick : 0u);
+                draw.coin = quad_or(j == rel ? mine.coin : 0u);
+            } else {
+                draw = policy_draw(pool, step);
+            }
+            const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
+            if (type != PULSE_AGENT_EXTERNAL) {
+                act64 = scripted_action(type, a_h0, a_h1, pot, draw);
+                if (j == 0) sto(actions, ut * 8u, (int64_t)act64);
+            }
+        }
+        const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
+
+        STAMP(3);   // policy done
+        // ---- 1) equities of dirty tables (PokerGPU.py:455-525)
+        if (PH & PULSE_PH_EQUITY) {
+            if (dirty) {
+                const int c5 = stage >= 2 ? b3 : 0, c6 = stage == 3 ? b4 : 0;
+                const bool street = stage >= 1 && stage <= 3;
+                const bool cached_board = street && board_matches(pre_tag, stage + 2, b0, b1, b2, b3, b4);
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) {
+                    const int seat = j + LPT * k;
+                    float e = 0.5f;
+                    if (seat < A && street) {
+                        int hc0 = h0[k], hc1 = h1[k];
+                        if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
+                        bool hit = false;
+                        if (cached_board) {       // the cache reads are independent single hops
+                            const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
+                            const float pe = ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
+                            hit = ph == pack_hand(hc0, hc1) && card_ok(hc0) && card_ok(hc1);
+                            e = pe;
+                        }
+                        if (!hit) {               // the reference's literal seven-gather chain
+                            const float r = (float)walk7(hr, hr_len, hc0, hc1, b0, b1, b2, c5, c6);
+                            e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
+                            e = fminf(fmaxf(e, 0.0f), 1.0f);
+                        }
+                    }
+                    eq[k] = e;
+                    if (seat < A) sto(v.equities, (eq0 + (uint32_t)seat) * 4u, e);
+                }
+                dirty = false; street_dirty = true;
+            }
+        }
+        float e_actor;
+        {
+            uint32_t r_ = 0;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == actor ? __float_as_uint(eq[k]) : 0u;
+            e_actor = __uint_as_float(quad_or(r_));
+            if (actor >= LPT * SPL) e_actor = 0.5f;
+        }
+
+        STAMP(4);   // equities done
+        // ---- 2) execute the action of the seat to act (PokerGPU.py:230-303)
+        if (PH & PULSE_PH_EXECUTE) {
+            const int call_cost = highest - a_bet;
+            const bool active = a_status != PULSE_FOLDED && a_status != PULSE_ALLIN && a_status != PULSE_SITOUT && !done;
+            if (active && action >= 0) {
+                int n_stack = a_stack, n_bet = a_bet, n_inv_add = 0, n_status = a_status;
+                if (action == 0) {
+                    n_status = PULSE_FOLDED;
+                } else {
+                    int raise_amt = 0;
+                    if (action == 2) raise_amt = lrs;
+                    else if (action == 12) raise_amt = a_stack;
+                    else if (action >= 3 && action <= 11) {
+                        const float fr = action == 3 ? 0.25f : action == 4 ? 0.33f : action == 5 ? 0.50f : action == 6 ? 0.75f
+                                       : action == 7 ? 1.00f : action == 8 ? 1.50f : action == 9 ? 2.00f : action == 10 ? 3.00f : 4.00f;
+                        raise_amt = (int)__fmul_rn((float)pot, fr);
+                    }
+                    const int total = action == 1 ? call_cost : call_cost + raise_amt;
+                    const int amt = min(total, a_stack);
+                    const bool is_raise = action >= 2 && amt > call_cost;
+                    n_stack = a_stack - amt; n_bet = a_bet + amt; n_inv_add = amt; pot += amt;
+                    if (n_stack == 0) n_status = PULSE_ALLIN;
+                    if (is_raise) {
+                        const int raise_size = n_bet - highest;
+                        highest = n_bet;
+                        if (raise_size >= lrs) { agg = idx; acted = 0; lrs = raise_size; }
+                    }
+                }
+                acted += 1;
+                bet_dirty = true;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k)
+                    if (j + LPT * k == (idx & 15)) { stack[k] = n_stack; bet[k] = n_bet; inv[k] += n_inv_add; status[k] = n_status; cells_dirty |= 1u << k; }
+            }
+        }
+
+        const uint32_t act_bits = SEAT_BITS(status[k] == PULSE_ACTIVE);
+        const uint32_t cont_bits = SEAT_BITS(status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
+        const int contenders = __popc(cont_bits);
+
+        STAMP(5);   // action executed, seat masks built
+        // ---- 3) next actor, round close, street transition (PokerGPU.py:547-616)
+        if (PH & PULSE_PH_ADVANCE) {
+            const int truly_active = __popc(act_bits);
+            const bool all_acted = acted >= truly_active;
+            bool round_over = done || truly_active == 0;
+            const uint32_t maskA = (1u << A) - 1u;
+            const int next_seat = first_after_near(act_bits & maskA, idx, A);
+            const bool has_next = next_seat >= 0;
+            const bool closes = all_acted && (idx == agg || (has_next && next_seat == agg));
+            round_over = round_over || !has_next || closes;
+            if (!round_over && has_next) { idx = next_seat; bet_dirty = true; }
+            const bool early_term = contenders <= 1 && round_over;
+            if (early_term) done = true;
+            if (round_over && !early_term && !done) {
+                lrs = 1; stage += 1; highest = 0; agg = mod_near(button + 1, A); acted = 0;
+                bet_dirty = true; street_dirty = true;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) { cells_dirty |= (bet[k] != 0 ? 1u : 0u) << k; bet[k] = 0; }
+                const int first = first_after_near(act_bits & maskA, button, A);
+                if (first >= 0) idx = first;
+                if (stage > 3) { done = true; stage = 4; }
+                else {
+                    const int32_t* dk = v.decks + (size_t)t * 52;
+                    const int nx0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    if (stage == 1) {                                                // burn + flop (:601-604)
+                        b0 = nx0;
+                        b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
+                        b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                        dpos += 4;
+                    }
+                    else if (stage == 2) { b3 = nx0; dpos += 2; }                    // burn + turn (:607-610)
+                    else { b4 = nx0; dpos += 2; }                                    // burn + river (:613-616)
+                    dirty = true; board_dirty = true;
+                }
+            }
+        }
+        // a chunk fetches the next actor's hole cards now; they are first needed by the observation below
+        int2 next_hand = make_int2(0, 0);
+        if (MULTI) next_hand = hand_of_seat(idx & 15);
+
+        STAMP(6);   // advance / deal done
+        // ---- 4) payouts on newly finished tables (PokerGPU.py:619-623)
+        const bool newly_done = (PH & PULSE_PH_CAPTURE) ? (done && !prev_done) : done;
+        if (PH & PULSE_PH_FOLDWIN) {                                            // :331-338
+            if (newly_done && contenders == 1) {
+                const int survivor = __ffs((int)cont_bits) - 1;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) if (j + LPT * k == survivor) { stack[k] += pot; cells_dirty |= 1u << k; }
+                pot = 0; bet_dirty = true;
+            }
+        }
+        if (PH & PULSE_PH_SHOWDOWN) {                                           // :380-453
+            if (newly_done && stage < 5 && contenders > 1) {
+                const int32_t* dk = v.decks + (size_t)t * 52;
+                if (stage == 0) {
+                    b0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
+                    b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                    b3 = (uint32_t)(dpos + 5) < 52u ? dk[dpos + 5] : 0;
+                    b4 = (uint32_t)(dpos + 7) < 52u ? dk[dpos + 7] : 0;
+                    dpos += 8;
+                } else if (stage == 1) {
+                    b3 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    b4 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                    dpos += 4;
+                } else if (stage == 2) {
+                    b4 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    dpos += 2;
+                }
+                bool eligible[SPL]; int rank[SPL], payout[SPL];
+                const bool cached_board = board_matches(pre_tag, 5, b0, b1, b2, b3, b4);
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) {
+                    const int seat = j + LPT * k;
+                    eligible[k] = seat < A && (status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
+                    rank[k] = INT_MIN; payout[k] = 0;
+                    if (eligible[k]) {
+                        int hc0 = h0[k], hc1 = h1[k];
+                        if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
+                        bool hit = false;
+                        if (cached_board) {
+                            const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
+                            const int pr = ldo(v.pre_rank, ROW_OFF(k));
+                            hit = ph == pack_hand(hc0, hc1) && card_ok(hc0) && card_ok(hc1);
+                            rank[k] = pr;
+                        }
+                        if (!hit) rank[k] = walk7(hr, hr_len, hc0, hc1, b0, b1, b2, b3, b4);
+                    }
+                }
+                // side pots, one layer per distinct commitment level (PokerGPU.py:340-378)
+                int prev_level = 0;
+                for (int l = 0; l < A; ++l) {
+                    int lv = INT_MAX;
+#pragma unroll
+                    for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] > prev_level) lv = min(lv, inv[k]);
+                    const int level = quad_imin(lv);
+                    if (level == INT_MAX) break;
+                    const int n_contrib = __popc(SEAT_BITS((j + LPT * k) < A && inv[k] >= level));
+                    int bl = INT_MIN;
+#pragma unroll
+                    for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] >= level && eligible[k]) bl = max(bl, rank[k]);
+                    const int best = quad_imax(bl);
+                    const uint32_t win_bits = SEAT_BITS((j + LPT * k) < A && inv[k] >= level && eligible[k] && rank[k] == best);
+                    const int n_win = __popc(win_bits);
+                    if (n_win > 0) {
+                        const int layer_pot = (level - prev_level) * n_contrib;
+                        const int share = layer_pot / n_win, rem = layer_pot - share * n_win;
+                        const int first_win = __ffs((int)win_bits) - 1;
+#pragma unroll
+                        for (int k = 0; k < SPL; ++k)
+                            if ((win_bits >> (j + LPT * k)) & 1u) payout[k] += share + ((j + LPT * k) == first_win ? rem : 0);
+                    }
+                    prev_level = level;
+                }
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) { stack[k] += payout[k]; cells_dirty |= (payout[k] != 0 ? 1u : 0u) << k; }
+                pot = 0; stage = 5;
+                bet_dirty = true; street_dirty = true; board_dirty = true;
+            }
+        }
+        if (PH & PULSE_PH_CLEARDONE) {                                          // :625-628
+            if (done) {
+                bet_dirty = bet_dirty || highest != 0;
+                highest = 0;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k) { cells_dirty |= ((bet[k] | inv[k]) != 0 ? 1u : 0u) << k; bet[k] = 0; inv[k] = 0; }
+            }
+        }
+
+        STAMP(7);   // payouts done
+        // ---- 5) shaped reward (PokerGPU.py:305-329, :631-632)
+        if (PH & PULSE_PH_REWARD) {
+            const float cnt = (float)contenders;
+            const float fair = __fdiv_rn(1.0f, fmaxf(cnt, 1.0f));
+            const int cc = max(0, highest - prev_invested);
+            const float potf = (float)pot;
+            const float m = __fmul_rn(e_actor, potf);
+            const float o = __fdiv_rn((float)cc, __fadd_rn((float)(pot + cc), 1e-6f));
+            float sv = 0.0f;
+            if (action == 1) sv = __fmul_rn(__fsub_rn(e_actor, o), potf);
+            else if (action == 0) sv = __fmul_rn(__fsub_rn(o, e_actor), potf);
+            else if (action >= 2) sv = __fmul_rn(__fsub_rn(e_actor, fair), potf);
+            const float x = __fdiv_rn(__fadd_rn(__fmul_rn(w1, m), __fmul_rn(w2, sv)), (float)Kdiv);
+            float r = __fmul_rn((float)alpha, tanh_rn(x));
+            if ((PH & PULSE_PH_CAPTURE) && (!has_legal_actor || prev_done)) r = 0.0f;
+            if (j == 0) sto(rew_dst, so, r);
+        }
+
+        STAMP(8);   // reward done
+        // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
+        if (PH & PULSE_PH_OBS) {
+            const int wlane = threadIdx.x & 63;
+            float* const l_obs = reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * 16 * v.obs_size;
+            float* __restrict__ o = WOBS ? l_obs + (wlane >> 2) * v.obs_size
+                                         : reinterpret_cast<float*>(reinterpret_cast<char*>(obs_dst) + __umul24(ut, (uint32_t)v.obs_size) * 4u);
+            const int seat_i = idx & 15;
+            const int n_h0 = MULTI ? next_hand.x : SEAT_PICK(h0, seat_i), n_h1 = MULTI ? next_hand.y : SEAT_PICK(h1, seat_i);
+            const int n_stack = SEAT_PICK(stack, seat_i), n_status = SEAT_PICK(status, seat_i), n_bet = SEAT_PICK(bet, seat_i);
+            if (MULTI) { a_status = n_status; a_stack = n_stack; a_bet = n_bet; a_h0 = n_h0; a_h1 = n_h1; }   // the next step's actor
+            const int idxm = mod_near(idx, A);
+            const int pos = mod_near(idx - button, A);
+            // columns 0..12, four per quad pass: lane j writes column 4*pass + j (a 4-way select per pass)
+            const int h0v = j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
+            const int h1v = j == 0 ? b4 : j == 1 ? n_h0 : j == 2 ? n_h1 : stage;
+            const int h2v = j == 0 ? pos : j == 1 ? pot : j == 2 ? highest - n_bet : n_stack;
+            o[j] = (float)h0v; o[4 + j] = (float)h1v; o[8 + j] = (float)h2v;
+            if (j == 0) o[12] = (float)n_status;
+            // opponents: seat (idx+1+k)%A -> columns 13+3k..; seats >= A zero-fill the padding slots
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                const int seat = j + LPT * k;
+                if (seat < v.max_players && seat != idxm) {
+                    int slot; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+                    if (seat < A) { slot = seat - idxm - 1; if (slot < 0) slot += A; f0 = (float)stack[k]; f1 = (float)status[k]; f2 = (float)bet[k]; }
+                    else slot = seat - 1;
+                    float* dst = o + 13 + 3 * slot;
+                    dst[0] = f0; dst[1] = f1; dst[2] = f2;
+                }
+            }
+            if (WOBS) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int n4 = 4 * v.obs_size;                                   // int4 per wavefront block
+                const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) << 4;   // first table of this wavefront
+                int4* dst = reinterpret_cast<int4*>(obs_dst + (size_t)tw0 * v.obs_size);
+                const int4* src = reinterpret_cast<const int4*>(smem4) + (threadIdx.x >> 6) * n4;
+                for (int e = wlane; e < n4; e += 64) dst[e] = src[e];
+                if (MULTI) {       // the next step's values must not overtake these reads of the slice
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        } else if (MULTI) {
+            // (not reachable: a chunk always has PULSE_PH_OBS) keep the carried actor consistent anyway
+            const int seat_i = idx & 15;
+            a_status = SEAT_PICK(status, seat_i); a_stack = SEAT_PICK(stack, seat_i); a_bet = SEAT_PICK(bet, seat_i);
+            a_h0 = next_hand.x; a_h1 = next_hand.y;
+        }
+        STAMP(9);   // observation stores issued
+        if ((PH & PULSE_PH_ADVANCE) && j == 0) sto(done_dst, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
+    }
+
+    // ---- store: the groups whose flag was raised (one test per seat / per group instead of one branch per word).
+    // In a chunk the ~25 state pointers would have to stay in scalar registers across the whole step loop (they were
+    // spilled, 95 of them); the kernel argument block is re-read here through a pointer the compiler cannot see through.
+    const char* kernarg = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (MULTI) asm volatile("" : "+s"(kernarg));
+    const PulsePokerView& vs = MULTI ? *reinterpret_cast<const PulsePokerView*>(kernarg) : v;   // the view is the first kernel argument
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int seat = j + LPT * k;
+        if (seat < P && ((cells_dirty >> k) & 1u)) {
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(vs.stacks, ROW_OFF(k), stack[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(vs.current_round_bet, ROW_OFF(k), bet[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) sto(vs.total_invested, ROW_OFF(k), inv[k]);
+            if (PH & PULSE_PH_EXECUTE) sto(vs.status, ROW_OFF(k), status[k]);
+        }
+    }
+    if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
+        if (board_dirty) {
+            sto(vs.board, bo + (uint32_t)j * 4u, j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3);
+            if (j == 0) sto(vs.board, bo + 16u, b4);
+        }
+    }
+    if (j == 0) {
+        if (PH & PULSE_PH_CAPTURE) { sto(vs.prev_stacks, so, prev_stack); sto(vs.prev_invested, so, prev_invested); }
+        if (bet_dirty) {
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(vs.pots, so, pot);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(vs.highest, so, highest);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { sto(vs.agg, so, agg); sto(vs.acted, so, acted); sto(vs.last_raise_size, so, lrs); }
+            if (PH & PULSE_PH_ADVANCE) sto(vs.idx, so, idx);
+        }
+        if (street_dirty) {
+            if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { sto(vs.stages, so, stage); sto(vs.deck_positions, so, dpos); }
+            if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) sto(vs.equity_dirty, ut, (uint8_t)(dirty ? 1 : 0));
+        }
+    }
+    if (POLICY && pa.wave_done) {
+        // the roll-out's stop rule (trainGPU.py:27-33) rides on the launch: every wavefront stores how many of its
+        // tables are done -- a plain store, summed on a side stream (atomics onto shared counters cost this launch
+        // as much as the separate counting kernel they would replace)
+        const int c = __popcll(__ballot(done && j == 0));
+        if ((threadIdx.x & 63) == 0) pa.wave_done[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = (uint32_t)c;
+    }
+    STAMP(10);  // state stores issued
+#if PULSE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);                      // vmcnt(0): all stores acknowledged
+    STAMP(11);
+#endif
+#undef SEAT_BITS
+#undef SEAT_PICK
+#undef ROW_OFF
+}
+
+// ---------------------------------------------------------------- host side
+inline dim3 step_grid(const PulsePokerView& v) { return dim3((unsigned)(((long long)v.n_games * LPT + kBlock - 1) / kBlock)); }
+inline int seats_per_lane(const PulsePokerView& v) { return (v.max_players + LPT - 1) / LPT; }   // covers max_players (obs padding too)
+inline bool obs_staging(const PulsePokerView& v, const float* obs_odd) {
+    return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games & 15) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
+}
+inline size_t obs_lds(const PulsePokerView& v) { return sizeof(float) * (size_t)(kBlock / 64) * 16 * (size_t)v.obs_size; }
+
+template <uint32_t PH, bool POLICY>
+void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa,
+                 hipStream_t st) {
+    const dim3 grid = step_grid(v), block(kBlock);
+    const ChunkArgs ca{nullptr, nullptr, 1};
+    const bool three = seats_per_lane(v) <= 3;
+    if (PH == PULSE_PH_STEP && obs_staging(v, nullptr)) {
+        constexpr bool W = PH == PULSE_PH_STEP;
+        if (three) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 3, W, false>), grid, block, obs_lds(v), st, v, actions, actor_idx, rewards, pa, ca);
+        else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, W, false>), grid, block, obs_lds(v), st, v, actions, actor_idx, rewards, pa, ca);
+    }
+    else if (three) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 3, false, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa, ca);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, false, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa, ca);
+}
+
+void launch_chunk(const PulsePokerView& v, int64_t* actions, float* rewards_even, const PolicyArgs& pa, const ChunkArgs& ca, hipStream_t st) {
+    const dim3 grid = step_grid(v), block(kBlock);
+    const bool three = seats_per_lane(v) <= 3;
+    constexpr uint32_t PH = PULSE_PH_STEP;
+    const int32_t* no_actor = nullptr;
+    if (obs_staging(v, ca.obs_odd)) {
+        if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, true, true>), grid, block, obs_lds(v), st, v, actions, no_actor, rewards_even, pa, ca);
+        else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, true, true>), grid, block, obs_lds(v), st, v, actions, no_actor, rewards_even, pa, ca);
+    }
+    else if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, false, true>), grid, block, 0, st, v, actions, no_actor, rewards_even, pa, ca);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, false, true>), grid, block, 0, st, v, actions, no_actor, rewards_even, pa, ca);
+}
+
+template <uint32_t PH>
+void launch_phase(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, hipStream_t st) {
+    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0, nullptr}, st);
+}
+
+}  // namespace
+
+// HIP-event timer owned by the caller: brackets whole roll-out calls on their launch stream
+struct PulseTimer {
+    static constexpr int kMax = 4096;
+    hipEvent_t start[kMax], stop[kMax];
+    int launches[kMax], steps[kMax];
+    int created = 0, used = 0;
+};
+
+extern "C" {
+
+int pulse_poker_step(const PulsePokerView* v, const int64_t* actions, float* rewards, void* stream) {
+    if (int rc = pulse::check_view(v, "pulse_poker_step")) return rc;
+    if (!actions || !rewards) return pulse::fail(PULSE_EINVAL, "pulse_poker_step: null actions/rewards");
+    if (v->n_games == 0) return 0;
+    launch_phase<PULSE_PH_STEP>(*v, const_cast<int64_t*>(actions), nullptr, rewards, (hipStream_t)stream);
+    return pulse::finish_launch("pulse_poker_step");
+}
+
+int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
+                            uint64_t table_id0, int64_t* actions, float* rewards, void* stream) {
+    if (int rc = pulse::check_view(v, "pulse_poker_policy_step")) return rc;
+    if (!actions || !rewards || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_policy_step: null argument");
+    if (v->n_games == 0) return 0;
+    const PolicyArgs pa{pulse::pack_types(agent_types, v->n_players), seed, step_counter, table_id0, nullptr};
+    launch_step<PULSE_PH_STEP, true>(*v, actions, nullptr, rewards, pa, (hipStream_t)stream);
+    return pulse::finish_launch("pulse_poker_policy_step");
+}
+
+int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* actions, const int32_t* actor_idx,
+                       float* rewards, void* stream) {
+    if (int rc = pulse::check_view(v, "pulse_poker_phases")) return rc;
+    if ((phases & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && !actions)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_phases: actions required for EXECUTE/REWARD");
+    if ((phases & PULSE_PH_REWARD) && !rewards) return pulse::fail(PULSE_EINVAL, "pulse_poker_phases: rewards required for REWARD");
+    if (v->n_games == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t* a = const_cast<int64_t*>(actions);
+    switch (phases) {
+    case PULSE_PH_STEP: launch_phase<PULSE_PH_STEP>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_STEP & ~PULSE_PH_EQUITY: launch_phase<(PULSE_PH_STEP & ~PULSE_PH_EQUITY)>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_EQUITY: launch_phase<PULSE_PH_EQUITY>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_EXECUTE: launch_phase<PULSE_PH_EXECUTE>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_ADVANCE: launch_phase<PULSE_PH_ADVANCE>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_FOLDWIN: launch_phase<PULSE_PH_FOLDWIN>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_SHOWDOWN: launch_phase<PULSE_PH_SHOWDOWN>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN: launch_phase<(PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_CLEARDONE: launch_phase<PULSE_PH_CLEARDONE>(*v, a, nullptr, rewards, st); break;
+    case PULSE_PH_REWARD: launch_phase<PULSE_PH_REWARD>(*v, a, actor_idx, rewards, st); break;
+    case PULSE_PH_OBS: launch_phase<PULSE_PH_OBS>(*v, a, nullptr, rewards, st); break;
+    default: return pulse::fail(PULSE_EINVAL, "pulse_poker_phases: unsupported phase combination");
+    }
+    return pulse::finish_launch("pulse_poker_phases");
+}
+
+/* Diagnostic (tools/ablate_step.py): the fused policy+step with some phases compiled out.
+ * Results are NOT a valid transition; used only to price phases. */
+int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* actions, float* rewards, uint64_t types_packed,
+                       uint64_t step_counter, void* stream) {
+    if (int rc = pulse::check_view(v, "pulse_poker_ablate")) return rc;
+    const dim3 grid = step_grid(*v), block(kBlock);
+    const PolicyArgs pa{types_packed, 1, step_counter, 0, nullptr};
+    const ChunkArgs ca{nullptr, nullptr, 1};
+    hipStream_t st = (hipStream_t)stream;
+#define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 3, false, false>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa, ca); break;
+    switch (phases) {
+    PULSE_ABL(PULSE_PH_STEP)
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_EQUITY)
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_SHOWDOWN)
+    PULSE_ABL(PULSE_PH_STEP & ~(PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN))
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_REWARD)
+    PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_OBS)
+    PULSE_ABL(PULSE_PH_STEP & ~(PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN | PULSE_PH_REWARD))
+    PULSE_ABL(PULSE_PH_STEP & ~(PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN | PULSE_PH_REWARD | PULSE_PH_OBS))
+    PULSE_ABL(PULSE_PH_CAPTURE)
+    default: return pulse::fail(PULSE_EINVAL, "pulse_poker_ablate: mask not instantiated");
+    }
+#undef PULSE_ABL
+    return pulse::finish_launch("pulse_poker_ablate");
+}
+
+#if PULSE_STAMPS
+int pulse_debug_set_stamp_buffer(unsigned long long* buf) {
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+    return e == hipSuccess ? 0 : pulse::fail_hip((int)e, "pulse_debug_set_stamp_buffer");
+}
+#endif
+
+/* ---- roll-out: n_steps fused policy+step transitions enqueued by one native call --------------------------- */
+int pulse_timer_create(void** out) {
+    if (!out) return pulse::fail(PULSE_EINVAL, "pulse_timer_create: null argument");
+    *out = new PulseTimer();
+    return 0;
+}
+
+int pulse_timer_destroy(void* timer) {
+    PulseTimer* tm = static_cast<PulseTimer*>(timer);
+    if (!tm) return 0;
+    for (int i = 0; i < tm->created; ++i) { (void)hipEventDestroy(tm->start[i]); (void)hipEventDestroy(tm->stop[i]); }
+    delete tm;
+    return 0;
+}
+
+int pulse_timer_collect(void* timer, float* sum_ms, int32_t* n_launches, int64_t* n_steps) {
+    PulseTimer* tm = static_cast<PulseTimer*>(timer);
+    if (!tm || !sum_ms || !n_launches || !n_steps) return pulse::fail(PULSE_EINVAL, "pulse_timer_collect: null argument");
+    float total = 0.0f; int launches = 0; long long steps = 0;
+    for (int i = 0; i < tm->used; ++i) {
+        float ms = 0.0f;
+        const hipError_t e = hipEventElapsedTime(&ms, tm->start[i], tm->stop[i]);
+        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_timer_collect (call it after a stream sync)");
+        total += ms; launches += tm->launches[i]; steps += tm->steps[i];
+    }
+    *sum_ms = total; *n_launches = launches; *n_steps = steps;
+    tm->used = 0;
+    return 0;
+}
+
+int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
+                        uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions, float* rewards_even,
+                        float* rewards_odd, int32_t n_steps, void* timer, void* stoprule, void* stream) {
+    if (int rc = pulse::check_view(v_even, "pulse_poker_rollout")) return rc;
+    if (int rc = pulse::check_view(v_odd, "pulse_poker_rollout")) return rc;
+    if (!actions || !rewards_even || !rewards_odd || !agent_types || n_steps < 0)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout: bad argument");
+    if (v_even->is_done != v_odd->is_done_out || v_even->is_done_out != v_odd->is_done || v_even->n_games != v_odd->n_games)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout: v_odd must be v_even with is_done / is_done_out swapped");
+    if (v_even->n_games == 0 || n_steps == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t packed = pulse::pack_types(agent_types, v_even->n_players);
+    const bool chunk = !(v_even->flags & PULSE_VIEW_NO_CHUNK);
+    PulseTimer* tm = static_cast<PulseTimer*>(timer);
+    const bool timed = tm && tm->used < PulseTimer::kMax;
+    if (timed) {
+        if (tm->used >= tm->created) {
+            if (hipEventCreate(&tm->start[tm->created]) != hipSuccess || hipEventCreate(&tm->stop[tm->created]) != hipSuccess)
+                return pulse::fail(PULSE_ENODEVICE, "pulse_poker_rollout: hipEventCreate failed");
+            ++tm->created;
+        }
+        const hipError_t e = hipEventRecord(tm->start[tm->used], st);
+        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_poker_rollout: hipEventRecord");
+    }
+    PulseStopRule* rule = static_cast<PulseStopRule*>(stoprule);
+    const int n_waves = (int)(((long long)v_even->n_games * LPT + 63) / 64);
+    uint32_t* wave_done = nullptr;
+    if (rule) if (int rc = pulse::stoprule_claim(rule, n_waves, &wave_done)) return rc;   // the slot must be free before the last launch writes into it
+    if (chunk) {
+        const PolicyArgs pa{packed, seed, step_counter0, table_id0, wave_done};
+        launch_chunk(*v_even, actions, rewards_even, pa, ChunkArgs{v_odd->obs, rewards_odd, n_steps}, st);
+    } else {
+        for (int i = 0; i < n_steps; ++i) {
+            const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
+            float* rw = (i & 1) ? rewards_odd : rewards_even;
+            const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0, i == n_steps - 1 ? wave_done : nullptr};
+            launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
+        }
+    }
+    if (timed) {
+        (void)hipEventRecord(tm->stop[tm->used], st);
+        tm->launches[tm->used] = chunk ? 1 : n_steps; tm->steps[tm->used] = n_steps; ++tm->used;
+    }
+    if (int rc = pulse::finish_launch("pulse_poker_rollout")) return rc;
+    if (rule) return pulse::stoprule_commit(rule, n_waves, st);
+    return 0;
+}
+
+}  // extern "C"

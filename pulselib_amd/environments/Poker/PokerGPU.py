@@ -15,7 +15,6 @@ Differences a caller can observe (all deliberate):
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -51,7 +50,7 @@ _ROWS = ("stacks", "current_round_bet", "total_invested", "status")
 _TRACKED = frozenset(_I32_SCALARS + _BOOL_SCALARS + _ROWS + ("hands", "board", "decks", "equities", "obs",
                                                              "w1", "w2", "K", "alpha", "hand_ranks",
                                                              "active_players", "n_players", "n_games", "max_players",
-                                                             "use_eval_cache"))
+                                                             "use_eval_cache", "obs_staging", "chunked_rollout"))
 
 
 class PokerGPU(_EnvBase):
@@ -95,7 +94,11 @@ class PokerGPU(_EnvBase):
         self.seed = int(seed)
         self.table_id0 = int(table_id0)
         self.episode = 0
-        self.use_eval_cache = os.environ.get("PULSE_EVAL_CACHE", "1") != "0"
+        # kernel variants, switchable per instance (PulsePokerView.flags / NULL cache pointers); the parity suite runs
+        # the same roll-outs with each of them off
+        self.use_eval_cache = True       # reset fills the evaluation cache, steps read it
+        self.obs_staging = True          # observations leave as LDS-staged 16-byte bursts (needs n_games % 16 == 0)
+        self.chunked_rollout = True      # rollout(): one launch per chunk of steps instead of one per step
         # opt-in: successive steps write their observation into two alternating buffers, so the tensor a step returned
         # stays intact through the NEXT step (a trainer then needs no copy of the pre-step observation).  Off: the
         # reference's single persistent buffer (PokerGPU.py:633).
@@ -226,6 +229,7 @@ class PokerGPU(_EnvBase):
             v = _native.PokerView()
             v.n_games, v.n_players, v.active_players, v.max_players = N, P, A, self.max_players
             v.obs_size, v.hand_ranks_len = self.obs_size, hr.numel()
+            v.flags = (0 if self.obs_staging else _native.VIEW_NO_OBS_STAGING) | (0 if self.chunked_rollout else _native.VIEW_NO_CHUNK)
             v.hand_ranks = hr.data_ptr()
             for k, p in ptr.items():
                 setattr(v, k, p)
@@ -347,11 +351,13 @@ class PokerGPU(_EnvBase):
         object.__setattr__(self, "obs", self._obs_bufs[pp])
         return self.obs, rewards, self.is_done, self.is_truncated, self.get_info()
 
-    def rollout(self, agent_types, actions, n_steps, step_counter0, time_every=0, stop_rule=None):
-        """`n_steps` fused policy+step launches enqueued back to back by the native library (no Python
-        between launches).  Equivalent to calling policy_step(agent_types, actions, step_counter0 + i)
-        for i in range(n_steps); returns what the last step returned.  `stop_rule` (stoprule.LaggedDoneCount):
-        its done-count of the final state is submitted by the same native call."""
+    def rollout(self, agent_types, actions, n_steps, step_counter0, timer=None, stop_rule=None):
+        """`n_steps` fused policy+step transitions in ONE native call and (chunked_rollout) ONE launch: the
+        tables' state stays in registers between the steps, every step still stores its observation, reward,
+        done flag and action.  Memory afterwards is bit-identical to calling
+        policy_step(agent_types, actions, step_counter0 + i) for i in range(n_steps); returns what the last step
+        returned.  `stop_rule` (stoprule.LaggedDoneCount): the done-count of the final state is submitted as one
+        check point by the same call; `timer` (stoprule.RolloutTimer): the call is bracketed by HIP events."""
         actions = self._actions(actions)
         key = tuple(int(x) for x in agent_types)
         types = self._types_cache.get(key)
@@ -365,7 +371,8 @@ class PokerGPU(_EnvBase):
         _native.check(self._lib.pulse_poker_rollout(C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types,
                                                     self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
                                                     actions.data_ptr(), self._rewards[pp].data_ptr(),
-                                                    self._rewards[1 - pp].data_ptr(), int(n_steps), int(time_every),
+                                                    self._rewards[1 - pp].data_ptr(), int(n_steps),
+                                                    None if timer is None else timer.handle,
                                                     None if stop_rule is None else stop_rule.handle,
                                                     self._stream()), "pulse_poker_rollout")
         if n_steps <= 0:

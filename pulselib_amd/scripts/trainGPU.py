@@ -99,9 +99,11 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
       the learner's update (`learner="native"`: train_step_native, three HIP launches; `"torch"`: train_step_masked on
       PyTorch autograd) -> every 5th step the lagged done-count.
     `active_players` is drawn from a host RNG (the reference reads a device randint back, PokerGPU.py:76-77) and the
-    stop rule is decided on the newest count that already reached the host (stoprule.py); `stop_rule="sync"`
-    restores the reference's blocking check, `"steps"` runs every episode to `max_episode_steps` (data-parallel runs:
-    the ranks' collectives must stay in step, and a rank-local stop decision would not).  Needs a learner with `act_into` / `train_step_masked` (qnetwork.py).
+    stop rule is decided one check point late, on the done count of the WHOLE job (stoprule.py: with one process per
+    GPU the count is all-reduced on a side stream, so every rank ends every episode at the same step and the learner's
+    gradient all-reduces and the episode statistics stay aligned); `stop_rule="sync"` restores the reference's blocking
+    check (lag 0), `"steps"` runs every episode to `max_episode_steps`.  Needs a learner with `act_into` /
+    `train_step_masked` (qnetwork.py).
     `hand_metrics` (utils.performance.HandMetrics) adds the BB/100 side-channel of trainGPU_performance.py:192-206 as
     one more launch per step; its per-episode summaries come back under "hand_metrics"."""
     import random
@@ -115,7 +117,11 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         raise TypeError("train_agent_fused needs a learner with act_into / train_step_native (PokerQNetwork)")
     native = learner == "native"
     host_rng = random.Random(host_seed)
-    done_count = LaggedDoneCount(device, n_games, TERMINATION_THRESHOLD)
+    if stop_rule not in ("lagged", "sync", "steps"):
+        raise ValueError(f"stop_rule must be 'lagged', 'sync' or 'steps', got {stop_rule!r}")
+    if stop_rule == "steps" and max_episode_steps is None:
+        raise ValueError("stop_rule='steps' needs max_episode_steps")
+    done_count = LaggedDoneCount(device, n_games, TERMINATION_THRESHOLD, lag=0 if stop_rule == "sync" else 1)
     actions = torch.zeros(n_games, dtype=torch.long, device=device)
     # the env alternates two observation buffers from here on: the tensor a step returned is still intact while the
     # next step runs, so the pre-step observation the learner needs is simply the previous `state` (no copy per step)
@@ -173,7 +179,7 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
             global_step += 1
             if idx % CHECK_INTERVAL == 0 and stop_rule != "steps":                    # :27-33 cadence
                 done_count.submit(terminated)
-                if done_count.over(blocking=stop_rule == "sync"):
+                if done_count.over():                                                 # the same verdict on every rank
                     break
             idx += 1
             if max_episode_steps is not None and idx >= max_episode_steps:
@@ -189,6 +195,7 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         total_steps += n_games * idx                                                  # :108
 
     torch.cuda.synchronize(device)
+    done_count.close()
     if double_buffered:
         env.double_buffer_obs = False
     end_time = time.time()

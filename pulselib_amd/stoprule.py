@@ -1,12 +1,21 @@
-"""Episode stop rule of the reference trainer without its host sync.
+"""Episode stop rule of the reference trainer without its host sync, on one GPU or on one process per GPU.
 
 scripts/Poker/trainGPU.py:27-33 ends an episode when, at every 5th step, `terminated.float().mean() > 0.8` -- a
-blocking device->host read in the middle of the loop.  `LaggedDoneCount` keeps the rule and drops the wait: after a
-chunk of steps the number of finished tables is counted on the device (cumulative counter: no memset in the loop),
-copied to pinned host memory on a side stream, and the decision is taken on the newest count that has ALREADY
-arrived -- normally the one of the previous chunk.  `blocking=True` waits for the current chunk's count instead (the
-reference's behaviour).  The mechanics live in the native library (pulse_stoprule_*, csrc/poker.hip): done through
-torch, the chunk boundary cost more host time than the chunk's five step launches take on the GPU."""
+blocking device->host read in the middle of the loop.  `LaggedDoneCount` keeps the rule and drops the wait: each
+check point ("chunk") counts the finished tables on the device, a side stream sums the count, all-reduces it over the
+ranks of the job and copies it to pinned host memory, and the verdict of chunk c is taken right after chunk c + lag
+has been enqueued.  The lag is FIXED (default 1), not "whatever has arrived": a run is reproducible, and every rank
+decides on the same chunk from the same global count, so all ranks end every episode at the same step and issue
+identical sequences of collectives.  `lag=0` is the reference's blocking check.
+
+Who exchanges the counts between ranks:
+  * `exchange="rccl"` (default with the nccl backend): the native library's own RCCL communicator, enqueued on the
+    rule's side stream by the same native call that enqueues the steps -- no Python, no host wait (csrc/stoprule.hip);
+  * `exchange="host"` (gloo, i.e. the CPU tests and the one-GPU rehearsal): the local count of the due chunk is read
+    from pinned memory and all-reduced with torch.distributed by `over()`;
+  * `exchange="local"` (one process): nothing to exchange.
+The mechanics live in the native library (pulse_stoprule_*): done through torch, the chunk boundary cost more host
+time than the chunk's five steps take on the GPU."""
 from __future__ import annotations
 
 import ctypes as C
@@ -16,35 +25,193 @@ import torch
 from . import _native
 
 
-class LaggedDoneCount:
-    def __init__(self, device, n_tables: int, threshold: float = 0.8):
-        self.device, self.n, self.threshold = device, int(n_tables), float(threshold)
+class NativeComm:
+    """RCCL communicator owned by the native library (pulse_comm_*), one rank per process / GPU.  The 128-byte
+    unique id travels over the already initialised torch.distributed group; creation is collective."""
+
+    def __init__(self, device, group=None):
+        import torch.distributed as dist
         self._lib = _native.lib()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _native.check(self._lib.pulse_comm_unique_id(buf), "pulse_comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if dist.get_backend(group) == "nccl":
+            ident = ident.to(device)
+        dist.broadcast(ident, src=0, group=group)
+        raw = (C.c_uint8 * 128)(*ident.cpu().tolist())
         h = C.c_void_p()
         with torch.cuda.device(device):
-            _native.check(self._lib.pulse_stoprule_create(self.n, self.threshold, C.byref(h)), "pulse_stoprule_create")
+            _native.check(self._lib.pulse_comm_create(raw, self.rank, self.world, C.byref(h)), "pulse_comm_create")
         self.handle = h
 
-    def submit(self, is_done: torch.Tensor) -> None:
-        """Count the set flags of `is_done` (bool/uint8[n]) in stream order and start the copy to the host.
-        (PokerGPU.rollout(..., stop_rule=self) does this inside the same native call as the step launches.)"""
-        _native.check(self._lib.pulse_stoprule_submit(self.handle, is_done.data_ptr(),
+    def all_reduce_i64_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks of a device int64 tensor, in the current stream's order."""
+        assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+        _native.check(self._lib.pulse_comm_all_reduce_i64(self.handle, t.data_ptr(), t.data_ptr(), t.numel(),
+                                                          torch.cuda.current_stream(t.device).cuda_stream), "pulse_comm_all_reduce_i64")
+        return t
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.pulse_comm_destroy(self.handle)
+            self.handle = None
+
+
+def _dist_world(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class HostCounts:
+    """The native rule's bookkeeping (csrc/stoprule.hip: submitted / epoch_first / fixed lag) for counts the caller
+    already holds on the host -- no device involved.  `LaggedDoneCount(..., backend=HostCounts(lag))` is what the
+    world-size-2 gloo tests drive on CPU; the product path uses the native handle."""
+
+    def __init__(self, lag: int = 1):
+        if not 0 <= lag < 4:
+            raise ValueError("need 0 <= lag < 4")
+        self.lag, self.submitted, self.epoch_first, self._counts = int(lag), 0, 0, {}
+
+    def submit_count(self, n_done: int) -> None:
+        self._counts[self.submitted] = int(n_done)
+        self._counts.pop(self.submitted - 4, None)
+        self.submitted += 1
+
+    def counts(self):
+        c = self.submitted - 1 - self.lag
+        if c < self.epoch_first:
+            return 0, 0, False
+        return self._counts[c], self._counts[c], True
+
+    def drain(self) -> None:
+        self.epoch_first = self.submitted
+
+    def close(self) -> None:
+        pass
+
+
+class LaggedDoneCount:
+    def __init__(self, device, n_tables: int, threshold: float = 0.8, lag: int = 1, n_global: int | None = None,
+                 exchange: str | None = None, group=None, comm: NativeComm | None = None, backend: HostCounts | None = None):
+        self.device, self.n, self.threshold, self.lag = device, int(n_tables), float(threshold), int(lag)
+        self.group = group
+        self.backend = backend
+        world = _dist_world(group)
+        if exchange is None:
+            if world == 1:
+                exchange = "local"
+            else:
+                import torch.distributed as dist
+                exchange = "rccl" if dist.get_backend(group) == "nccl" else "host"
+        if exchange not in ("local", "host", "rccl"):
+            raise ValueError(f"exchange must be 'local', 'host' or 'rccl', got {exchange!r}")
+        if backend is not None and exchange == "rccl":
+            raise ValueError("a host-side count backend cannot use the native RCCL exchange")
+        if exchange != "local" and world == 1:
+            exchange = "local"
+        self.exchange = exchange
+        self.n_global = int(n_global) if n_global is not None else (self.n if exchange == "local" else None)
+        if self.n_global is None:
+            import torch.distributed as dist
+            t = torch.tensor([self.n], dtype=torch.int64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, group=group)
+            self.n_global = int(t.item())
+        self.decisions = 0            # verdicts taken so far (the world-size-2 tests compare this across ranks)
+        self.exchanges = 0            # host-side all-reduces issued by over()
+        self._own_comm = None
+        self.comm = None
+        self.handle = None
+        if backend is not None:
+            if backend.lag != self.lag:
+                raise ValueError("backend.lag differs from lag")
+            return
+        self._lib = _native.lib()
+        if exchange == "rccl" and comm is None:
+            comm = self._own_comm = NativeComm(device, group)
+        self.comm = comm if exchange == "rccl" else None
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _native.check(self._lib.pulse_stoprule_create(self.n, self.n_global, self.threshold, self.lag,
+                                                          self.comm.handle if self.comm is not None else None, C.byref(h)),
+                          "pulse_stoprule_create")
+        self.handle = h
+
+    def submit(self, flags: torch.Tensor) -> None:
+        """One check point: count the set flags of `flags` (bool/uint8[n]) in stream order.
+        (PokerGPU.rollout(..., stop_rule=self) does this inside the native call that enqueues the steps.)"""
+        if self.backend is not None:
+            self.backend.submit_count(int(flags.sum()))
+            return
+        _native.check(self._lib.pulse_stoprule_submit(self.handle, flags.data_ptr(), flags.numel(),
                                                       torch.cuda.current_stream(self.device).cuda_stream), "pulse_stoprule_submit")
 
-    def over(self, blocking: bool = False) -> bool:
-        """True if any count that has reached the host since the last call exceeds the threshold."""
+    def counts(self):
+        """(local, global, have) of the chunk whose verdict is due: the one submitted `lag` chunks before the newest."""
+        if self.backend is not None:
+            return self.backend.counts()
+        loc, glob, have = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        _native.check(self._lib.pulse_stoprule_counts(self.handle, C.byref(loc), C.byref(glob), C.byref(have)), "pulse_stoprule_counts")
+        return loc.value, glob.value, bool(have.value)
+
+    def over(self) -> bool:
+        """Verdict of the due chunk (False while no chunk of this episode is due).  Identical on every rank."""
+        if self.exchange == "host":
+            import torch.distributed as dist
+            loc, _, have = self.counts()
+            if not have:                      # the same on every rank: chunk indices advance in lock step
+                return False
+            t = torch.tensor([loc], dtype=torch.int64)
+            dist.all_reduce(t, group=self.group)
+            self.decisions += 1
+            self.exchanges += 1
+            return float(t.item()) > self.threshold * self.n_global
+        if self.backend is not None:
+            _, glob, have = self.backend.counts()
+            self.decisions += 1
+            return have and glob > self.threshold * self.n_global
         flag = C.c_int32(0)
-        _native.check(self._lib.pulse_stoprule_over(self.handle, 1 if blocking else 0, C.byref(flag)), "pulse_stoprule_over")
+        _native.check(self._lib.pulse_stoprule_decide(self.handle, C.byref(flag)), "pulse_stoprule_decide")
+        self.decisions += 1
         return bool(flag.value)
 
     def drain(self) -> None:
-        """Episode boundary: consume what is in flight so the cumulative counters stay consistent."""
+        """Episode boundary: the chunks submitted so far decide nothing any more."""
+        if self.backend is not None:
+            self.backend.drain()
+            return
         _native.check(self._lib.pulse_stoprule_drain(self.handle), "pulse_stoprule_drain")
 
     def close(self) -> None:
         if getattr(self, "handle", None):
             self._lib.pulse_stoprule_destroy(self.handle)
             self.handle = None
+        if self._own_comm is not None:
+            self._own_comm.close()
+            self._own_comm = None
 
     # no __del__: at interpreter shutdown the HIP runtime may already be gone, and an unclosed handle only leaks a side
-    # stream, four events and 16 bytes; long-lived callers call close()
+    # stream, eight events and < 1 MB; long-lived callers call close()
+
+
+class RolloutTimer:
+    """HIP-event pairs around native roll-out calls on their launch stream (pulse_timer_*)."""
+
+    def __init__(self):
+        self._lib = _native.lib()
+        h = C.c_void_p()
+        _native.check(self._lib.pulse_timer_create(C.byref(h)), "pulse_timer_create")
+        self.handle = h
+
+    def collect(self):
+        """(sum of milliseconds, launches, steps) of the calls bracketed since the last collect; sync the stream first."""
+        ms, n_l, n_s = C.c_float(0), C.c_int32(0), C.c_int64(0)
+        _native.check(self._lib.pulse_timer_collect(self.handle, C.byref(ms), C.byref(n_l), C.byref(n_s)), "pulse_timer_collect")
+        return ms.value, n_l.value, n_s.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.pulse_timer_destroy(self.handle)
+            self.handle = None

@@ -127,13 +127,20 @@ def _seeded_decks(n, seed):
     return (torch.rand((n, 52), generator=g).argsort(dim=1) + 1).to(torch.int32)
 
 
-@pytest.mark.parametrize("N,P,As", [(65536, 10, (10, 7, 2)), (4099, 6, (6, 3)), (1, 2, (2,)), (17, 16, (16, 9))])
-def test_hip_matches_oracle_at_scale(oracle_table, N, P, As):
-    """Config-2 size (65,536 tables, 10 seats) and ragged sizes: every step compared with the oracle."""
+@pytest.mark.parametrize("variant", ["default", "no_eval_cache", "no_obs_staging"])
+@pytest.mark.parametrize("N,P,As", [(65536, 10, (10, 7, 2)), (4099, 6, (6, 3)), (4096, 6, (6, 3)), (1, 2, (2,)), (17, 16, (16, 9))])
+def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
+    """Config-2 size (65,536 tables, 10 seats) and ragged sizes: every step compared with the oracle -- with the
+    product defaults and with each kernel variant switched off (evaluation cache -> the reference's literal gather
+    chains; LDS-staged observation bursts -> column stores), per instance."""
     from oracle import oracle as orc
+    if variant != "default" and N > 10000:
+        pytest.skip("variants are covered at 4,096 / 4,099 tables")
     MP = max(P, 10)
     kw = dict(n_players=P, max_players=MP, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
     env = _gpu_env(**kw)
+    env.use_eval_cache = variant != "no_eval_cache"
+    env.obs_staging = variant != "no_obs_staging"
     ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
     rng = np.random.default_rng(N + P)
     tol = reward_tol(50)
@@ -185,7 +192,7 @@ def test_device_table_digest_matches_golden(golden_dir):
     assert hashlib.sha256(handranks.host_table().tobytes()).hexdigest() == str(vec["sha256"])
 
 
-@pytest.mark.parametrize("launcher", ["policy_step", "rollout", "policy_then_step"])
+@pytest.mark.parametrize("launcher", ["policy_step", "rollout", "rollout_per_step", "policy_then_step"])
 def test_fused_policy_step_matches_oracle(oracle_table, launcher):
     """Scripted opponents fused with the step (one launch) follow the oracle's policy+step trajectory
     bit for bit: same Philox stream, same masks (Player.py:79-176), same transition."""
@@ -194,6 +201,7 @@ def test_fused_policy_step_matches_oracle(oracle_table, launcher):
     N, P = 8192, 10
     kw = dict(n_players=P, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
     env = _gpu_env(seed=777, table_id0=5000, **kw)
+    env.chunked_rollout = launcher != "rollout_per_step"
     ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
     types = [0, 3, 2, 2, 4, 3, 1, 4, 5, 3]      # seat 0 external (caller's action), the rest pokerGPU.yaml's mix
     rng = np.random.default_rng(3)
@@ -207,8 +215,8 @@ def test_fused_policy_step_matches_oracle(oracle_table, launcher):
             ext = rng.integers(0, 13, N).astype(np.int64)
             a_ref = ext.copy()
             a_gpu = torch.from_numpy(ext.copy()).to(DEV)
-            if launcher == "rollout":
-                n = 4
+            if launcher.startswith("rollout"):
+                n = 5 if s % 2 else 4
                 # EXTERNAL seats re-read the same buffer every step of the chunk on both sides
                 env.rollout(types, a_gpu, n, gstep)
                 for i in range(n):
@@ -520,49 +528,109 @@ def test_hip_matches_oracle_at_config4_shard_size(oracle_table):
     assert total == ref.stacks.sum(dtype=np.int64) + ref.pots.sum(dtype=np.int64)
 
 
-def test_native_stop_rule_counts_lags_and_drains():
+def test_native_stop_rule_fixed_lag_counts_and_drains():
     """pulselib_amd.stoprule.LaggedDoneCount (pulse_stoprule_*): the rule of trainGPU.py:27-33 -- more than 80 % of the
-    tables done -- on counts copied back asynchronously; cumulative device counters, two submissions in flight at most."""
+    tables done -- decided on the check point submitted `lag` check points before the newest one (a FIXED lag: the
+    verdict sequence is a function of the submitted flags only, never of copy timing)."""
     from pulselib_amd.stoprule import LaggedDoneCount
     dev = torch.device(DEV)
     n = 10000
-    rule = LaggedDoneCount(dev, n, 0.8)
+    rule = LaggedDoneCount(dev, n, 0.8, lag=0)        # lag 0 = the reference's blocking check
     flags = torch.zeros(n, dtype=torch.bool, device=dev)
+    assert rule.over() is False                      # nothing submitted yet
     rule.submit(flags)
-    assert rule.over(blocking=True) is False
+    assert rule.over() is False
     flags[:8000] = True                              # exactly 80 %: not over ("> 0.8")
     rule.submit(flags)
-    assert rule.over(blocking=True) is False
+    assert rule.counts() == (8000, 8000, True) and rule.over() is False
     flags[8000] = True
     rule.submit(flags)
-    assert rule.over(blocking=True) is True
-    assert rule.over(blocking=True) is False         # a decision is reported once
-    # run-ahead: several submissions without polling keep the newest verdicts, none is lost
-    flags.zero_()
-    for k in range(5):
-        if k == 2:
-            flags[:9000] = True
-        if k == 3:
+    assert rule.over() is True
+    rule.close()
+    for lag in (1, 2, 3):
+        r = LaggedDoneCount(dev, n, 0.8, lag=lag)
+        fracs = [0.0, 0.5, 0.9, 0.1, 0.85, 0.85, 0.2, 0.95]
+        verdicts = []
+        for f in fracs:
             flags.zero_()
-        rule.submit(flags)
-    assert rule.over(blocking=True) is True          # submission 2 was over the threshold
-    rule.submit(flags)
-    rule.drain()
-    assert rule.over(blocking=False) is False
-    # inside the native rollout call: the done flags of the state the last launch produced
-    env = _gpu_env(n_players=6, max_players=10, n_games=4096, seed=3)
-    env.reset(options={"active_players": 6})
-    r2 = LaggedDoneCount(dev, 4096, 0.8)
-    actions = torch.zeros(4096, dtype=torch.long, device=dev)
-    types = [1, 1, 1, 1, 1, 1]                       # every seat plays `random`: hands end within a few dozen steps
-    over_at = None
-    for chunk in range(40):
-        env.rollout(types, actions, 5, 5 * chunk, stop_rule=r2)
-        if r2.over(blocking=True):
-            over_at = chunk
-            break
-    assert over_at is not None and env.is_done.float().mean().item() > 0.8
-    rule.close(); r2.close()
+            flags[:int(f * n)] = True
+            r.submit(flags)
+            verdicts.append(r.over())
+        want = [False] * lag + [f > 0.8 for f in fracs[:len(fracs) - lag]]
+        assert verdicts == want, (lag, verdicts, want)
+        # an episode boundary: what was submitted before it decides nothing afterwards
+        flags.fill_(True)
+        r.submit(flags)
+        r.drain()
+        flags.zero_()
+        after = []
+        for _ in range(lag + 2):
+            r.submit(flags)
+            after.append(r.over())
+        assert after == [False] * (lag + 2), (lag, after)
+        r.close()
+    with pytest.raises(ValueError):
+        LaggedDoneCount(dev, n, 0.8, lag=4)
+    # inside the native rollout call: the done flags of the state the last step produced, chunked or not
+    for chunked in (True, False):
+        env = _gpu_env(n_players=6, max_players=10, n_games=4096, seed=3)
+        env.chunked_rollout = chunked
+        env.reset(options={"active_players": 6})
+        r2 = LaggedDoneCount(dev, 4096, 0.8, lag=1)
+        actions = torch.zeros(4096, dtype=torch.long, device=dev)
+        types = [1, 1, 1, 1, 1, 1]                       # every seat plays `random`: hands end within a few dozen steps
+        over_at, fr = None, []
+        for chunk in range(40):
+            env.rollout(types, actions, 5, 5 * chunk, stop_rule=r2)
+            fr.append(env.is_done.float().mean().item())
+            if r2.over():
+                over_at = chunk
+                break
+        # the verdict at chunk c is chunk c-1's count
+        assert over_at is not None and over_at >= 1 and fr[over_at - 1] > 0.8 and all(f <= 0.8 for f in fr[:over_at - 1])
+        loc, glob, have = r2.counts()
+        assert have and loc == glob == int(round(fr[over_at - 1] * 4096))
+        r2.close()
+
+
+ROLLOUT_MEMORY = INT_KEYS + ("decks", "equities", "prev_stacks", "prev_invested", "equity_dirty")
+
+
+@pytest.mark.parametrize("N,P,MP", [(4096, 10, 10), (4099, 10, 10), (17, 6, 10), (1, 2, 2), (2048, 16, 16), (1040, 13, 16)],
+                         ids=["4096x10", "ragged4099", "17x6", "1x2", "2048x16", "1040x13of16"])
+@pytest.mark.parametrize("dbl", [False, True], ids=["one-obs-buffer", "two-obs-buffers"])
+def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl):
+    """pulse_poker_rollout as ONE launch per chunk (state in registers across the steps) against the same call issuing
+    one launch per step (PULSE_VIEW_NO_CHUNK): every state tensor, BOTH observation buffers, BOTH reward buffers, both
+    done buffers and the actions are bit-identical after every chunk -- chunk lengths 1..19 from odd and even step
+    counters (the Philox pool of a chunk covers eight steps, longer chunks refill it), across episodes."""
+    kw = dict(n_players=P, max_players=MP, n_games=N, w1=.5, w2=.3, K=100, alpha=50, seed=91, table_id0=7)
+    one, per = _gpu_env(**kw), _gpu_env(**kw)
+    per.chunked_rollout = False
+    one.double_buffer_obs = per.double_buffer_obs = dbl
+    types = ([0, 3, 2, 2, 4, 3, 1, 4, 5, 3, 1, 2, 3, 4, 5, 1])[:P]          # seat 0 external
+    rng = np.random.default_rng(5)
+    gstep = 3
+    for e, A in enumerate((P, max(2, P // 2), P)):
+        for env in (one, per):
+            env.reset(options={"active_players": A, "rotation": e})
+        for n in (1, 2, 5, 7, 8, 5, 19, 3, 5):
+            ext = torch.from_numpy(rng.integers(0, 13, N)).to(DEV)
+            acts = [ext.clone(), ext.clone()]
+            outs = [env.rollout(types, a, n, gstep) for env, a in zip((one, per), acts)]
+            gstep += n
+            ctx = f"N{N} e{e} chunk {n} @ {gstep}"
+            for name in ROLLOUT_MEMORY:
+                np.testing.assert_array_equal(to_np(getattr(one, name)), to_np(getattr(per, name)), err_msg=f"{ctx} {name}")
+            np.testing.assert_array_equal(to_np(acts[0]), to_np(acts[1]), err_msg=ctx + " actions")
+            for k in range(2):
+                np.testing.assert_array_equal(to_np(one._obs_bufs[k]), to_np(per._obs_bufs[k]), err_msg=f"{ctx} obs buffer {k}")
+                np.testing.assert_array_equal(to_np(one._rewards[k]), to_np(per._rewards[k]), err_msg=f"{ctx} rewards buffer {k}")
+                np.testing.assert_array_equal(to_np(one._done_bufs[k]), to_np(per._done_bufs[k]), err_msg=f"{ctx} done buffer {k}")
+            assert one._pp == per._pp
+            for x, y in zip(outs[0][:3], outs[1][:3]):          # what the call returns: last observation, rewards, dones
+                np.testing.assert_array_equal(to_np(x), to_np(y), err_msg=ctx + " returned")
+    assert to_np(one.is_done).mean() > 0.3
 
 
 def test_stats_kernel_forms():

@@ -52,8 +52,6 @@ def main():
                    w1=.5, w2=.3, K=100, alpha=50, seed=20260401, table_id0=rank * args.tables)
     run = train_agent_fused if args.loop == "fused" else train_agent
     kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=world > 1)
-    if world > 1:
-        kw["stop_rule"] = "steps"                 # every rank must take the same number of steps per episode (collectives inside)
     if args.loop == "fused":
         kw["learner"] = args.learner
     run(env, agents, types, args.warmup, args.tables, device, **kw)
