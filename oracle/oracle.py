@@ -242,6 +242,17 @@ def eval_hands(hr: np.ndarray, cards: np.ndarray) -> np.ndarray:
     return out
 
 
+def scripted_actions_rows(types, c1, c2, pot, pick: int, coin: int, actions=None) -> np.ndarray:
+    """oracle_scripted_action over rows with the two draw words given (oracle/poker_oracle.c)."""
+    types = np.ascontiguousarray(types, dtype=np.uint8)
+    c1, c2, pot = (np.ascontiguousarray(x, dtype=np.int32) for x in (c1, c2, pot))
+    out = np.full(types.size, -7, dtype=np.int64) if actions is None else actions
+    lib().oracle_scripted_actions_rows(types.ctypes.data_as(C.c_void_p), c1.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p),
+                                       pot.ctypes.data_as(C.c_void_p), C.c_int(types.size), C.c_uint32(pick), C.c_uint32(coin),
+                                       out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def shuffle_decks(seed: int, table_id0: int, episode: int, n_tables: int, key_bits: int = 0) -> np.ndarray:
     """The device shuffle's definition (oracle/poker_oracle.c: oracle_shuffle_decks) -> int32[n_tables, 52]."""
     decks = np.zeros((n_tables, 52), dtype=np.int32)

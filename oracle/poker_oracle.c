@@ -483,6 +483,15 @@ int oracle_scripted_action(int type, int c1, int c2, int pot, const uint32_t rnd
     return a;
 }
 
+/* the same over rows with given draws (tests: the reference's policies are recorded with their draws forced to the
+ * ends of their ranges, tests/golden/scripted.npz); type 0 rows are left untouched, as build_actions leaves EXTERNAL seats */
+void oracle_scripted_actions_rows(const uint8_t* types, const int32_t* c1, const int32_t* c2, const int32_t* pot, int n,
+                                  uint32_t pick, uint32_t coin, int64_t* actions) {
+    const uint32_t rnd[2] = {pick, coin};
+    for (int i = 0; i < n; i++)
+        if (types[i]) actions[i] = oracle_scripted_action(types[i], c1[i], c2[i], pot[i], rnd);
+}
+
 /* The scripted opponents' draw for (table, step) -- the definition the HIP kernels are held to: one Philox call
  * serves two consecutive steps, call = Philox4x32-10(seed, table id, step >> 1); an even step takes words (x, y) of
  * the call, an odd step (z, w).  (torch's generator stream of the reference cannot be reproduced in a kernel; only

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void poker_hand_metrics_kernel(const uint8_
         if (!dones[t] || (terminated_before && terminated_before[t])) continue;
         const long long delta = (long long)stacks[(size_t)t * n_players + q_seat] - (long long)initial_q_stacks[t];
         const int pos = pymod(q_seat - button[t], active_players);
-        const int st = stages[t], bucket = st >= 4 ? 4 : max(st, 0);
+        const int bucket = min(max(stages[t], 0), 4);                         // 0..3 the street, 4 = showdown (stage codes 4 and 5)
         unsigned long long* cell = h + ((pos & (PULSE_MAX_SEATS - 1)) * 5 + bucket) * 4;
         atomicAdd(cell + 0, 1ull);
         if (delta > 0) atomicAdd(cell + 1, 1ull);

@@ -133,6 +133,15 @@ template <class T> __device__ __forceinline__ void sto(T* __restrict__ base, uin
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = val;
 }
 
+// The same store from inside a long loop: the byte offset passes through an empty asm, so the address cannot be
+// hoisted out of the loop as a 64-bit per-lane pointer (two VGPRs alive across the whole loop per store site, which
+// the register allocator then spills -- and a spill reload is a vector-memory load that waits behind every store in
+// flight); it is re-formed where it is used as scalar base + 32-bit lane offset.
+template <class T> __device__ __forceinline__ void sto_in_loop(T* base, uint32_t byte_off, T val) {
+    asm volatile("" : "+v"(byte_off));
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = val;
+}
+
 // ---------------------------------------------------------------- DPP cross-lane steps (no LDS traffic)
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;                               // quad_perm:[1,0,3,2] / [2,3,0,1]

@@ -24,6 +24,11 @@ namespace {
 
 constexpr int LPT = 4;        // lanes per table (one DPP quad)
 
+// dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
+// (hole cards [16][P_][2], cache tags [16][P_], ranks [16][P_], street equities [16][3][P_], deck window [16][8]);
+// 16-byte aligned so that the observation block of the next wavefront is.
+__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats) { return (16 * obs_size + 16 * seats * 7 + 16 * 8 + 3) & ~3; }
+
 struct PolicyArgs {
     uint64_t types_packed, seed, step_counter, table_id0;
     uint32_t* wave_done;                   // nullptr, or one word per wavefront of the launch: tables done after the last step
@@ -101,10 +106,71 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
         }
         if (seat < A) eq[k] = ldo(v.equities, (eq0 + (uint32_t)seat) * 4u);
     }
-    // hole cards of one seat / of this lane's seat k, from memory (chunk) or from the registers loaded above
-    auto hand_of_seat = [&](int seat) -> int2 {        // seat in 0..15: what SEAT_PICK(h0/h1, seat) yields
-        if (seat < P) return ldo(reinterpret_cast<const int2*>(v.hands), (row0 + (uint32_t)seat) * 8u);
-        return seat < LPT * SPL ? make_int2(-1, -1) : make_int2(0, 0);
+    // ---- chunk only: the read-only rows the steps consult (hole cards, the evaluation cache, the next cards of the deck)
+    // are staged in the wavefront's LDS slice ONCE.  A global load inside the step loop would have to be waited for
+    // with s_waitcnt vmcnt, which counts stores too -- i.e. for every observation / reward / done store of the
+    // previous step (the profile showed wavefronts parked there half of their life); LDS reads wait for nothing.
+    constexpr int P_ = LPT * SPL;                                       // seats per table as staged (12 or 16)
+    const int wave = threadIdx.x >> 6, q = (threadIdx.x & 63) >> 2;      // wavefront of the workgroup, table of the wavefront
+    int32_t* const lw = reinterpret_cast<int32_t*>(smem4) + wave * chunk_lds_dwords(v.obs_size, P_);
+    int32_t* const l_hands = lw + 16 * v.obs_size;                       // [16][P_][2]
+    int32_t* const l_prehands = l_hands + 16 * P_ * 2;                   // [16][P_]
+    int32_t* const l_prerank = l_prehands + 16 * P_;                     // [16][P_]
+    float* const l_preeq = reinterpret_cast<float*>(l_prerank + 16 * P_);   // [16][3][P_]
+    int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + 16 * 3 * P_);   // [16][8]: cards at deck position dpos0 + 0..7
+    const int dpos0 = dpos;
+    const bool cache_on = (PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board;
+    if (MULTI) {
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            const int seat = j + LPT * k;
+            int2 h = make_int2(-1, -1);
+            int ph = 0, pr = 0; float e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;
+            if (seat < P) {
+                h = ldo(reinterpret_cast<const int2*>(v.hands), ROW_OFF(k) * 2u);
+                if (cache_on) {
+                    ph = ldo(v.pre_hands, ROW_OFF(k)); pr = ldo(v.pre_rank, ROW_OFF(k));
+                    const uint32_t e0 = (__umul24(ut * 3u, (uint32_t)P) + (uint32_t)seat) * 4u, es = (uint32_t)P * 4u;
+                    e1 = ldo(v.pre_eq, e0); e2 = ldo(v.pre_eq, e0 + es); e3 = ldo(v.pre_eq, e0 + 2u * es);
+                }
+            }
+            *reinterpret_cast<int2*>(l_hands + (q * P_ + seat) * 2) = h;
+            l_prehands[q * P_ + seat] = ph; l_prerank[q * P_ + seat] = pr;
+            l_preeq[(q * 3 + 0) * P_ + seat] = e1; l_preeq[(q * 3 + 1) * P_ + seat] = e2; l_preeq[(q * 3 + 2) * P_ + seat] = e3;
+        }
+        const int32_t* dk = v.decks + (size_t)t * 52;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int at = dpos0 + 2 * j + e;
+            l_deck[q * 8 + 2 * j + e] = (uint32_t)at < 52u ? dk[at] : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // hole cards of one seat, as every lane of the table may ask: what SEAT_PICK(h0/h1, seat) yields (seat in 0..15)
+    auto hand_of_seat = [&](int seat) -> int2 {
+        if (seat < P_) return *reinterpret_cast<const int2*>(l_hands + (q * P_ + seat) * 2);
+        return make_int2(0, 0);
+    };
+    // card at deck position `at`: from the staged window.  A hand deals at most 8 positions past its first street, so
+    // only a poked state can leave the window; it is then refilled from `at` on -- inside this branch, loads waited for
+    // here -- so that the ordinary path holds no global load (and no vmcnt wait at the join) at all.
+    int dwin0 = dpos0;
+    auto deck_card = [&](int at) -> int {
+        if (!MULTI) return (uint32_t)at < 52u ? v.decks[(size_t)t * 52 + at] : 0;
+        if ((uint32_t)(at - dwin0) >= 8u) {                         // table-uniform: the four lanes compute the same `at`
+            dwin0 = at;
+            const int32_t* dk = v.decks + (size_t)t * 52;
+            const int a0 = at + 2 * j, a1 = at + 2 * j + 1;
+            const int c0 = (uint32_t)a0 < 52u ? dk[a0] : 0, c1 = (uint32_t)a1 < 52u ? dk[a1] : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            l_deck[q * 8 + 2 * j] = c0; l_deck[q * 8 + 2 * j + 1] = c1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return l_deck[q * 8 + (at - dwin0)];
     };
     long long act64 = 0;
     if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = ldo(actions, ut * 8u);
@@ -144,11 +210,12 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
         a_h0 = h.x; a_h1 = h.y;
     }
     const int n_steps = MULTI ? ca.n_steps : 1;
+    // output buffers of this step / of the next one: swapped at the end of every step (scalar moves; a select on the
+    // step's parity made the compiler keep both sets of per-lane addresses alive across the loop -- and spill them)
+    float* obs_dst = v.obs; float* obs_nxt = MULTI ? ca.obs_odd : v.obs;
+    uint8_t* done_dst = v.is_done_out; uint8_t* done_nxt = v.is_done;
+    float* rew_dst = rewards; float* rew_nxt = MULTI ? ca.rewards_odd : rewards;
     for (int i = 0; i < n_steps; ++i) {
-        const bool odd = MULTI && (i & 1);
-        float* __restrict__ const obs_dst = odd ? ca.obs_odd : v.obs;
-        uint8_t* __restrict__ const done_dst = odd ? v.is_done : v.is_done_out;
-        float* __restrict__ const rew_dst = odd ? ca.rewards_odd : rewards;
 
         // ---- capture (PokerGPU.py:530-539)
         const bool prev_done = done;
@@ -183,7 +250,7 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
             const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
             if (type != PULSE_AGENT_EXTERNAL) {
                 act64 = scripted_action(type, a_h0, a_h1, pot, draw);
-                if (j == 0) sto(actions, ut * 8u, (int64_t)act64);
+                if (j == 0) sto_in_loop(actions, ut * 8u, (int64_t)act64);
             }
         }
         const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
@@ -204,8 +271,9 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                         if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
                         bool hit = false;
                         if (cached_board) {       // the cache reads are independent single hops
-                            const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
-                            const float pe = ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
+                            const uint32_t ph = MULTI ? (uint32_t)l_prehands[q * P_ + seat] : (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
+                            const float pe = MULTI ? l_preeq[(q * 3 + (stage - 1)) * P_ + seat]
+                                                   : ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
                             hit = ph == pack_hand(hc0, hc1) && card_ok(hc0) && card_ok(hc1);
                             e = pe;
                         }
@@ -216,7 +284,7 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                         }
                     }
                     eq[k] = e;
-                    if (seat < A) sto(v.equities, (eq0 + (uint32_t)seat) * 4u, e);
+                    if (seat < A) sto_in_loop(v.equities, (eq0 + (uint32_t)seat) * 4u, e);
                 }
                 dirty = false; street_dirty = true;
             }
@@ -294,12 +362,11 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                 if (first >= 0) idx = first;
                 if (stage > 3) { done = true; stage = 4; }
                 else {
-                    const int32_t* dk = v.decks + (size_t)t * 52;
-                    const int nx0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    const int nx0 = deck_card(dpos + 1);
                     if (stage == 1) {                                                // burn + flop (:601-604)
                         b0 = nx0;
-                        b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
-                        b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                        b1 = deck_card(dpos + 2);
+                        b2 = deck_card(dpos + 3);
                         dpos += 4;
                     }
                     else if (stage == 2) { b3 = nx0; dpos += 2; }                    // burn + turn (:607-610)
@@ -325,20 +392,15 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
         }
         if (PH & PULSE_PH_SHOWDOWN) {                                           // :380-453
             if (newly_done && stage < 5 && contenders > 1) {
-                const int32_t* dk = v.decks + (size_t)t * 52;
                 if (stage == 0) {
-                    b0 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
-                    b1 = (uint32_t)(dpos + 2) < 52u ? dk[dpos + 2] : 0;
-                    b2 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
-                    b3 = (uint32_t)(dpos + 5) < 52u ? dk[dpos + 5] : 0;
-                    b4 = (uint32_t)(dpos + 7) < 52u ? dk[dpos + 7] : 0;
+                    b0 = deck_card(dpos + 1); b1 = deck_card(dpos + 2); b2 = deck_card(dpos + 3);
+                    b3 = deck_card(dpos + 5); b4 = deck_card(dpos + 7);
                     dpos += 8;
                 } else if (stage == 1) {
-                    b3 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
-                    b4 = (uint32_t)(dpos + 3) < 52u ? dk[dpos + 3] : 0;
+                    b3 = deck_card(dpos + 1); b4 = deck_card(dpos + 3);
                     dpos += 4;
                 } else if (stage == 2) {
-                    b4 = (uint32_t)(dpos + 1) < 52u ? dk[dpos + 1] : 0;
+                    b4 = deck_card(dpos + 1);
                     dpos += 2;
                 }
                 bool eligible[SPL]; int rank[SPL], payout[SPL];
@@ -353,12 +415,15 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                         if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
                         bool hit = false;
                         if (cached_board) {
-                            const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
-                            const int pr = ldo(v.pre_rank, ROW_OFF(k));
+                            const uint32_t ph = MULTI ? (uint32_t)l_prehands[q * P_ + seat] : (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
+                            const int pr = MULTI ? l_prerank[q * P_ + seat] : ldo(v.pre_rank, ROW_OFF(k));
                             hit = ph == pack_hand(hc0, hc1) && card_ok(hc0) && card_ok(hc1);
                             rank[k] = pr;
                         }
-                        if (!hit) rank[k] = walk7(hr, hr_len, hc0, hc1, b0, b1, b2, b3, b4);
+                        if (!hit) {
+                            rank[k] = walk7(hr, hr_len, hc0, hc1, b0, b1, b2, b3, b4);
+                            asm volatile("" : "+v"(rank[k]));      // the chain's last load is waited for HERE, not at the join every table passes
+                        }
                     }
                 }
                 // side pots, one layer per distinct commitment level (PokerGPU.py:340-378)
@@ -417,14 +482,14 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
             const float x = __fdiv_rn(__fadd_rn(__fmul_rn(w1, m), __fmul_rn(w2, sv)), (float)Kdiv);
             float r = __fmul_rn((float)alpha, tanh_rn(x));
             if ((PH & PULSE_PH_CAPTURE) && (!has_legal_actor || prev_done)) r = 0.0f;
-            if (j == 0) sto(rew_dst, so, r);
+            if (j == 0) sto_in_loop(rew_dst, so, r);
         }
 
         STAMP(8);   // reward done
         // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
         if (PH & PULSE_PH_OBS) {
             const int wlane = threadIdx.x & 63;
-            float* const l_obs = reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * 16 * v.obs_size;
+            float* const l_obs = MULTI ? reinterpret_cast<float*>(lw) : reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * 16 * v.obs_size;
             float* __restrict__ o = WOBS ? l_obs + (wlane >> 2) * v.obs_size
                                          : reinterpret_cast<float*>(reinterpret_cast<char*>(obs_dst) + __umul24(ut, (uint32_t)v.obs_size) * 4u);
             const int seat_i = idx & 15;
@@ -457,9 +522,9 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int n4 = 4 * v.obs_size;                                   // int4 per wavefront block
                 const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) << 4;   // first table of this wavefront
-                int4* dst = reinterpret_cast<int4*>(obs_dst + (size_t)tw0 * v.obs_size);
-                const int4* src = reinterpret_cast<const int4*>(smem4) + (threadIdx.x >> 6) * n4;
-                for (int e = wlane; e < n4; e += 64) dst[e] = src[e];
+                const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
+                const int4* src = reinterpret_cast<const int4*>(l_obs);
+                for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
                 if (MULTI) {       // the next step's values must not overtake these reads of the slice
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -473,7 +538,12 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
             a_h0 = next_hand.x; a_h1 = next_hand.y;
         }
         STAMP(9);   // observation stores issued
-        if ((PH & PULSE_PH_ADVANCE) && j == 0) sto(done_dst, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
+        if ((PH & PULSE_PH_ADVANCE) && j == 0) sto_in_loop(done_dst, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
+        if (MULTI) {
+            float* fo = obs_dst; obs_dst = obs_nxt; obs_nxt = fo;
+            uint8_t* fd = done_dst; done_dst = done_nxt; done_nxt = fd;
+            float* fr = rew_dst; rew_dst = rew_nxt; rew_nxt = fr;
+        }
     }
 
     // ---- store: the groups whose flag was raised (one test per seat / per group instead of one branch per word).
@@ -556,12 +626,13 @@ void launch_chunk(const PulsePokerView& v, int64_t* actions, float* rewards_even
     const bool three = seats_per_lane(v) <= 3;
     constexpr uint32_t PH = PULSE_PH_STEP;
     const int32_t* no_actor = nullptr;
+    const size_t lds = sizeof(int32_t) * (size_t)(kBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, three ? 12 : 16);
     if (obs_staging(v, ca.obs_odd)) {
-        if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, true, true>), grid, block, obs_lds(v), st, v, actions, no_actor, rewards_even, pa, ca);
-        else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, true, true>), grid, block, obs_lds(v), st, v, actions, no_actor, rewards_even, pa, ca);
+        if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, true, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
+        else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, true, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
     }
-    else if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, false, true>), grid, block, 0, st, v, actions, no_actor, rewards_even, pa, ca);
-    else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, false, true>), grid, block, 0, st, v, actions, no_actor, rewards_even, pa, ca);
+    else if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, false, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, false, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
 }
 
 template <uint32_t PH>

@@ -41,6 +41,11 @@ class Particle2D(_EnvBase):
         self.terminated = torch.zeros(batch_size, device=device, dtype=torch.bool)
         self.steps = torch.zeros(batch_size, device=device, dtype=torch.int32)
         self._truncated = torch.zeros(batch_size, device=device, dtype=torch.bool)     # constant (Particle2D.py:30)
+        # step() returns fresh tensors in the reference (state.clone(), :26-30); here two persistent sets alternate, so
+        # what a step returned stays intact through the NEXT step and no allocation happens per call
+        self._out = [(torch.empty((batch_size, 4), device=device), torch.empty(batch_size, device=device),
+                      torch.empty(batch_size, device=device, dtype=torch.bool)) for _ in range(2)]
+        self._pp = 0
 
     def reset(self, seed=None, options=None):                       # Particle2D.py:15-20
         if seed is not None:
@@ -55,11 +60,11 @@ class Particle2D(_EnvBase):
         return self.state.clone(), {}
 
     def step(self, action):                                         # Particle2D.py:22-30
-        action = torch.as_tensor(action, dtype=torch.float32).to(self.device).contiguous()
+        if not (isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.device == self.device and action.is_contiguous()):
+            action = torch.as_tensor(action, dtype=torch.float32).to(self.device).contiguous()
         assert action.shape == (self.batch_size, 2)
-        obs = torch.empty_like(self.state)
-        rewards = torch.empty(self.batch_size, device=self.device)
-        terminated = torch.empty(self.batch_size, device=self.device, dtype=torch.bool)
+        obs, rewards, terminated = self._out[self._pp]
+        self._pp ^= 1
         _native.check(self._lib.pulse_particle2d_step(self.state.data_ptr(), action.data_ptr(), self.steps.data_ptr(),
                                                       obs.data_ptr(), rewards.data_ptr(), terminated.data_ptr(),
                                                       self.batch_size, float(self.dt), int(self.max_steps),

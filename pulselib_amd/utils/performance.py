@@ -49,13 +49,14 @@ class HandMetrics:
         self.device, self.n = device, int(n_tables)
         self.acc = torch.zeros(MAX_SEATS * BUCKETS * 4, dtype=torch.int64, device=device)
         self.initial = torch.zeros(self.n, dtype=torch.int32, device=device)
-        self.totals = {}                     # player_count -> int64[16,5,4] on the host
-        self.q_seat, self.active_players = 0, 2
+        self.totals = {}                     # (player_count, opponent-mix id) -> int64[16,5,4] on the host
+        self.q_seat, self.active_players, self.mix_id = 0, 2, 0
         self._lib = _native.lib()
 
-    def begin_episode(self, env, q_seat: int) -> None:
-        """after env.reset: remember the learner's starting stacks (trainGPU_performance.py:165)"""
-        self.q_seat, self.active_players = int(q_seat), int(env.active_players)
+    def begin_episode(self, env, q_seat: int, mix_id: int = 0) -> None:
+        """after env.reset: remember the learner's starting stacks (trainGPU_performance.py:165); `mix_id` labels the
+        episode's opponent pool for the `opponent_mix` slices (:288-297)"""
+        self.q_seat, self.active_players, self.mix_id = int(q_seat), int(env.active_players), int(mix_id)
         self.initial.copy_(env.stacks[:, self.q_seat])
         self.acc.zero_()
 
@@ -73,44 +74,78 @@ class HandMetrics:
         """One read-back per episode (at the point where the trainer reads its episode sums anyway); returns the
         episode's summary with the keys of summarize_episode_performance_metrics (:138-167)."""
         a = self.acc.cpu().numpy().reshape(MAX_SEATS, BUCKETS, 4).copy()
-        tot = self.totals.setdefault(self.active_players, np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64))
+        tot = self.totals.setdefault((self.active_players, self.mix_id), np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64))
         tot += a
         hands, wins, total = int(a[..., 0].sum()), int(a[..., 1].sum()), float(a[..., 2].sum())
         return {"mean_bb_delta": total / hands if hands else 0.0, "hand_win_rate": wins / hands if hands else 0.0,
                 "hands_completed": hands, "field_bb_per_100": bb_per_100(hands, total)}
 
     def summary(self) -> dict:
-        """The hand-derived part of calculate_final_performance_metrics (:352-...): totals, BB/100 with its lower bound,
-        seat-balanced BB/100 (:242-253), win share by street (:176-196), win rate by position (:199-221) and the BB/100
-        slices by seat / player count / street depth (:256-318) with the worst slice (:321-349)."""
-        if not self.totals:
-            allt = np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64)
-        else:
-            allt = sum(self.totals.values())
-        hands, wins = int(allt[..., 0].sum()), int(allt[..., 1].sum())
-        total, total_sq = float(allt[..., 2].sum()), float(allt[..., 3].sum())
-        by_pos = allt.sum(axis=1)            # [16, 4]
-        by_street = allt.sum(axis=0)         # [5, 4]
-        seats = [p for p in range(MAX_SEATS) if by_pos[p, 0] > 0]
-        seat_slices = {f"position_{p}": bb_per_100(int(by_pos[p, 0]), float(by_pos[p, 2])) for p in seats}
-        slices = {
-            "seat": seat_slices,
-            "player_count": {f"players_{a}": bb_per_100(int(t[..., 0].sum()), float(t[..., 2].sum())) for a, t in sorted(self.totals.items())
-                             if t[..., 0].sum() > 0},
-            "street_depth": {STREET_DEPTH_NAMES[b]: bb_per_100(int(by_street[b, 0]), float(by_street[b, 2])) for b in range(BUCKETS)
-                             if by_street[b, 0] > 0},
-        }
-        worst = min(((v, fam, name) for fam, d in slices.items() for name, v in d.items()), default=(0.0, "", ""))
-        return {
-            "total_hands": hands,
-            "total_bb_won": total,
-            "overall_hand_win_rate": wins / hands if hands else 0.0,
-            "field_bb_per_100": bb_per_100(hands, total),
-            "lcb95_bb_per_100": lcb95_bb_per_100(hands, total, total_sq),
-            "seat_balanced_bb_per_100": float(np.mean(list(seat_slices.values()))) if seat_slices else 0.0,
-            "street_win_percentages": {STREET_DEPTH_NAMES[b]: (int(by_street[b, 1]) / hands if hands else 0.0) for b in range(BUCKETS)},
-            "position_win_rates": {f"position_{p}": {"hands": int(by_pos[p, 0]), "wins": int(by_pos[p, 1]),
-                                                     "win_rate": int(by_pos[p, 1]) / int(by_pos[p, 0])} for p in seats},
-            "slices": slices,
-            "worst_slice": {"bb_per_100": worst[0], "family": worst[1], "slice": worst[2]},
-        }
+        return summarize_totals(self.totals)
+
+
+def accumulate_hands(deltas, stages, positions, player_counts, mix_ids=None) -> dict:
+    """The sufficient statistics pulse_poker_hand_metrics keeps on the device, built on the host from per-hand lists
+    (chip delta, terminal stage, button-relative position, player count and opponent-mix id of the episode):
+    {(player_count, mix_id): int64[16,5,4]} with cells {hands, wins, sum delta, sum delta^2}; stage buckets as
+    bucketize_terminal_stages (:170-173)."""
+    totals = {}
+    d = np.asarray(deltas, dtype=np.int64)
+    b = np.where(np.asarray(stages) >= 4, 4, np.clip(np.asarray(stages), 0, 3))
+    pos, cnt = np.asarray(positions, dtype=np.int64), np.asarray(player_counts, dtype=np.int64)
+    mix = np.zeros_like(cnt) if mix_ids is None else np.asarray(mix_ids, dtype=np.int64)
+    for a, x in sorted(set(zip(cnt.tolist(), mix.tolist()))):
+        t = totals.setdefault((int(a), int(x)), np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64))
+        m = (cnt == a) & (mix == x)
+        np.add.at(t[..., 0], (pos[m], b[m]), 1)
+        np.add.at(t[..., 1], (pos[m], b[m]), (d[m] > 0).astype(np.int64))
+        np.add.at(t[..., 2], (pos[m], b[m]), d[m])
+        np.add.at(t[..., 3], (pos[m], b[m]), d[m] * d[m])
+    return totals
+
+
+def summarize_totals(totals: dict) -> dict:
+    """The hand-derived part of calculate_final_performance_metrics (:352-...): totals, BB/100 with its lower bound,
+    seat-balanced BB/100 (:242-253), win share by street (:176-196), win rate by position (:199-221) and the BB/100
+    slices by opponent mix / seat / player count / street depth (:256-318) with the worst slice (:321-349, first
+    minimum in that family order).  `totals` = {(player_count, mix_id): int64[16,5,4]} (HandMetrics.totals /
+    accumulate_hands)."""
+    if not totals:
+        allt = np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64)
+    else:
+        allt = sum(totals.values())
+    hands, wins = int(allt[..., 0].sum()), int(allt[..., 1].sum())
+    total, total_sq = float(allt[..., 2].sum()), float(allt[..., 3].sum())
+    by_pos = allt.sum(axis=1)            # [16, 4]
+    by_street = allt.sum(axis=0)         # [5, 4]
+    seats = [p for p in range(MAX_SEATS) if by_pos[p, 0] > 0]
+    seat_slices = {f"position_{p}": bb_per_100(int(by_pos[p, 0]), float(by_pos[p, 2])) for p in seats}
+    def grouped(which):
+        g = {}
+        for key, t in totals.items():
+            g[key[which]] = g.get(key[which], 0) + t
+        return sorted(g.items())
+
+    slices = {
+        "opponent_mix": {f"mix_{x}": bb_per_100(int(t[..., 0].sum()), float(t[..., 2].sum())) for x, t in grouped(1) if t[..., 0].sum() > 0},
+        "seat": seat_slices,
+        "player_count": {f"players_{a}": bb_per_100(int(t[..., 0].sum()), float(t[..., 2].sum())) for a, t in grouped(0)
+                         if t[..., 0].sum() > 0},
+        "street_depth": {STREET_DEPTH_NAMES[b]: bb_per_100(int(by_street[b, 0]), float(by_street[b, 2])) for b in range(BUCKETS)
+                         if by_street[b, 0] > 0},
+    }
+    flat = [(v, fam, name) for fam, d in slices.items() for name, v in d.items()]
+    worst = min(flat, key=lambda x: x[0]) if flat else (0.0, "", "")          # first minimum, like argmin (:339-341)
+    return {
+        "total_hands": hands,
+        "total_bb_won": total,
+        "overall_hand_win_rate": wins / hands if hands else 0.0,
+        "field_bb_per_100": bb_per_100(hands, total),
+        "lcb95_bb_per_100": lcb95_bb_per_100(hands, total, total_sq),
+        "seat_balanced_bb_per_100": float(np.mean(list(seat_slices.values()))) if seat_slices else 0.0,
+        "street_win_percentages": {STREET_DEPTH_NAMES[b]: (int(by_street[b, 1]) / hands if hands else 0.0) for b in range(BUCKETS)},
+        "position_win_rates": {f"position_{p}": {"hands": int(by_pos[p, 0]), "wins": int(by_pos[p, 1]),
+                                                 "win_rate": int(by_pos[p, 1]) / int(by_pos[p, 0])} for p in seats},
+        "slices": slices,
+        "worst_slice": {"bb_per_100": worst[0], "family": worst[1], "slice": worst[2]},
+    }

@@ -44,6 +44,14 @@ def test_hand_metrics_match_per_hand_lists():
         assert abs(got["mean_bb_delta"] - e.mean()) < 1e-9 and abs(got["hand_win_rate"] - (e > 0).mean()) < 1e-12
         assert abs(got["field_bb_per_100"] - 100 * e.mean()) < 1e-7
     d = np.concatenate(deltas); st = np.concatenate(stages); po = np.concatenate(positions); pc = np.concatenate(counts)
+    # the device sums are exactly the sufficient statistics of the per-hand lists gathered the reference's way; what
+    # summarize_totals makes of them is pinned to utils/performance.py itself by tests/test_reference_pins.py
+    from pulselib_amd.utils.performance import accumulate_hands
+    want_totals = accumulate_hands(d.astype(np.int64), st, po, pc)
+    assert sorted(hm.totals) == sorted(want_totals)
+    for key in want_totals:
+        bad = np.argwhere(hm.totals[key] != want_totals[key])
+        assert bad.size == 0, f"{key}: cells [position, bucket, stat] {bad.tolist()}: device {hm.totals[key][tuple(bad.T)].tolist()} lists {want_totals[key][tuple(bad.T)].tolist()}"
     bucket = np.where(st >= 4, 4, np.clip(st, 0, 3))                               # utils/performance.py:170-173
     s = hm.summary()
     assert s["total_hands"] == d.size and s["total_bb_won"] == d.sum()

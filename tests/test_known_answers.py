@@ -62,3 +62,24 @@ def _oracle_env(oracle_table):
 @pytest.mark.parametrize("sc", SCENARIOS, ids=[s["name"] for s in SCENARIOS])
 def test_oracle_reproduces_reference_known_answers(sc, oracle_table):
     run_scenario(sc, *_oracle_env(oracle_table))
+
+
+# ---- the rest of the reference's white-box scenarios, as op lists (tests/scenarios_ops.py) ---------------------------
+from tests.scenario_runner import OracleAdapter, run_ops  # noqa: E402
+from tests.scenarios_ops import SCENARIOS as OP_SCENARIOS  # noqa: E402
+
+
+def test_op_scenarios_cover_the_reference_acceptance_list():
+    """scripts/Poker/test_poker_gpu_logic_runner.py:810-841 runs the logic matrix + the contract files; every family of
+    that list is restated (names are ours, sources are cited per scenario)."""
+    names = [s["name"] for s in OP_SCENARIOS]
+    assert len(names) == len(set(names)) and len(names) >= 90
+    families = {n.split("/")[0] for n in names}
+    assert {"actions", "observation", "reset", "termination", "heads-up", "no-actor", "equity", "round", "street", "showdown",
+            "step", "reward", "reset-rotation", "setup", "round-progression"} <= families
+    assert all(s["src"].startswith("test_poker_gpu_") for s in OP_SCENARIOS)
+
+
+@pytest.mark.parametrize("sc", OP_SCENARIOS, ids=[s["name"] for s in OP_SCENARIOS])
+def test_oracle_reproduces_reference_op_scenarios(sc, oracle_table):
+    run_ops(sc, OracleAdapter(oracle_table))

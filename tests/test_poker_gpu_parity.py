@@ -315,6 +315,17 @@ def test_hip_reproduces_reference_known_answers(sc):
     run_scenario(sc, *_hip_env_api())
 
 
+from tests.scenario_runner import HipAdapter, run_ops  # noqa: E402
+from tests.scenarios_ops import SCENARIOS as OP_SCENARIOS  # noqa: E402
+
+
+@pytest.mark.parametrize("sc", OP_SCENARIOS, ids=[s["name"] for s in OP_SCENARIOS])
+def test_hip_reproduces_reference_op_scenarios(sc):
+    """The reference's white-box tests (logic matrix, round progression, heads-up opening, reset rotation, street actor
+    reset, reset batch and action / terminal contracts) restated as data in tests/scenarios_ops.py, on the HIP path."""
+    run_ops(sc, HipAdapter(DEV))
+
+
 def test_reset_rejects_misshaped_prefixed_decks():
     env = _gpu_env(n_players=3, max_players=3, n_games=2)
     with pytest.raises(ValueError, match="prefixed_decks must have shape"):     # PokerGPU.py:91
@@ -460,6 +471,73 @@ def test_poker_reward_gpu_contracts_and_oracle(oracle_table):
     want = np.array([orc.lib().oracle_reward(C.byref(s), C.c_int(t), C.c_int64(int(acts[t])), C.c_int(int(actor[t]))) for t in range(N)],
                     dtype=np.float32)
     np.testing.assert_allclose(got, want, rtol=0, atol=reward_tol(11))
+
+
+def _allowed(corner_actions):
+    """Action set the reference's policy can produce for a row, from its four forced-draw corners (tests/golden/scripted.npz):
+    [lo..hi] without the rand() raise, united with [lo..hi] with it."""
+    a = corner_actions.astype(np.int64)
+    return (a[0], a[1]), (a[2], a[3])
+
+
+def _check_against_reference_classes(got, corner_actions, ctx):
+    (lo0, hi0), (lo1, hi1) = _allowed(corner_actions)
+    ok = ((got >= lo0) & (got <= hi0)) | ((got >= lo1) & (got <= hi1))
+    assert ok.all(), f"{ctx}: {np.flatnonzero(~ok)[:5]} got {got[~ok][:5]}"
+    det = (lo0 == hi0) & (lo1 == hi1) & (lo0 == lo1)
+    np.testing.assert_array_equal(got[det], lo0[det], err_msg=ctx + " (rows where the reference's policy is deterministic)")
+    return det
+
+
+NATIVE_BY_NAME = {"random": 1, "heuristic_hands": 2, "tight_aggressive": 3, "loose_passive": 4, "small_ball": 5}
+
+
+@pytest.mark.parametrize("form", ["standalone", "fused_step", "fused_chunk"])
+def test_hip_scripted_policies_follow_the_reference_classes(golden_dir, form):
+    """The HIP policies (stand-alone pulse_poker_policy over observations; fused in front of the step, single launch and
+    chunk) against the action classes recorded from the reference's four scripted players and build_actions
+    (Player.py:79-176, utils.py:108-123): fold / call exactly, raises inside the reference's range, every value of
+    the range drawn."""
+    from pulselib_amd.environments.Poker.utils import launch_policy, set_policy_seed
+    fx = np.load(golden_dir / "scripted.npz")
+    rows = fx["rows"].astype(np.int32)
+    n = rows.shape[0]
+    names = [str(x) for x in fx["build/type_names"]]
+    native = [NATIVE_BY_NAME[t] for t in names]
+    cases = [(f"{t} at every seat", [NATIVE_BY_NAME[t]] * 10, np.zeros(n, dtype=np.int32) + 3, fx[f"actions/{t}"])
+             for t in ("heuristic_hands", "tight_aggressive", "loose_passive", "small_ball")]
+    cases.append(("build_actions mix", native, fx["build/seat_idx"].astype(np.int32), fx["build/actions"]))
+    for ctx, types, seat, want in cases:
+        actions = torch.full((n,), -7, dtype=torch.long, device=DEV)
+        if form == "standalone":
+            obs = torch.zeros((n, 40), dtype=torch.float32, device=DEV)
+            obs[:, 5], obs[:, 6], obs[:, 9] = (torch.from_numpy(rows[:, k].astype(np.float32)).to(DEV) for k in range(3))
+            set_policy_seed(4242)
+            launch_policy(obs, actions, torch.from_numpy(seat).to(DEV), types, table_id0=17, step_counter=33)
+        else:
+            env = _gpu_env(n_players=10, max_players=10, n_games=n, seed=4242, table_id0=17)
+            env.reset(options={"active_players": 10})
+            t = torch.arange(n, device=DEV)
+            seat_t = torch.from_numpy(seat).to(DEV)
+            env.idx.copy_(seat_t)
+            env.hands[t, seat_t.long(), 0] = torch.from_numpy(rows[:, 0]).to(DEV)
+            env.hands[t, seat_t.long(), 1] = torch.from_numpy(rows[:, 1]).to(DEV)
+            env.pots.copy_(torch.from_numpy(rows[:, 2]).to(DEV))
+            if form == "fused_step":
+                env.policy_step(types, actions, 33)
+            else:
+                env.rollout(types, actions, 1, 33)
+        got = actions.cpu().numpy()
+        det = _check_against_reference_classes(got, want, f"{form}: {ctx}")
+        (lo0, hi0), (lo1, hi1) = _allowed(want)
+        spread = (~det) & (hi0 > lo0)
+        if spread.any():                              # every action of a raise range shows up among the rows that can raise
+            lo, hi = int(lo0[spread].min()), int(hi0[spread].max())
+            assert set(range(lo, hi + 1)) <= set(got[spread].tolist()), f"{form}: {ctx}: raise values missing"
+        coin_rows = (lo0 == hi0) & (lo1 != lo0)       # loose_passive's call rows: ~10 % of them raise (rand() > .9)
+        if coin_rows.sum() > 500:
+            frac = (got[coin_rows] != lo0[coin_rows]).mean()
+            assert 0.06 < frac < 0.14, f"{form}: {ctx}: raise share {frac:.3f}"
 
 
 def test_scripted_policy_masks_and_distributions():

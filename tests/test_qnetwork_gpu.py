@@ -361,7 +361,7 @@ def test_fused_trainer_with_hand_metrics_side_channel(g):
     assert len(hm["episodes"]) == 3 and hm["final"]["total_hands"] == sum(e["hands_completed"] for e in hm["episodes"]) > 0
     # chips are conserved per table, so what the learner's seat won over the finished hands is what the episodes report
     assert abs(hm["final"]["total_bb_won"]) <= 100 * hm["final"]["total_hands"]
-    assert set(hm["final"]["slices"]) == {"seat", "player_count", "street_depth"}
+    assert set(hm["final"]["slices"]) == {"opponent_mix", "seat", "player_count", "street_depth"}
 
 
 @pytest.mark.parametrize("state_dim,n_actions", [(16, 4), (24, 32), (13, 1), (64, 13)])

@@ -18,6 +18,7 @@ import bench  # noqa: E402
 from pulselib_amd.environments.Poker import PokerGPU  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5          # steps per launch: stamps 2..9 are those of the LAST step of the chunk
 dev = torch.device("cuda:0")
 lib = _native.lib()
 lib.pulse_debug_set_stamp_buffer.argtypes = [C.c_void_p]
@@ -40,7 +41,7 @@ for A, warm in ((8, 6), (8, 20), (6, 33)):
     for r in range(reps):
         buf.zero_()
         lib.pulse_debug_set_stamp_buffer(buf.data_ptr())
-        env.rollout(native, actions, 1, 1000 + r)
+        env.rollout(native, actions, STEPS, 1000 + 10 * r)
         torch.cuda.synchronize()
         st = buf.cpu().numpy().astype(np.int64)
         d = np.diff(st[:, :12], axis=1)
@@ -48,7 +49,7 @@ for A, warm in ((8, 6), (8, 20), (6, 33)):
         total.append((st[:, 11].max() - st[:, 0].min(), (st[:, 11] - st[:, 0]).mean(), st[:, 0].max() - st[:, 0].min()))
     lib.pulse_debug_set_stamp_buffer(None)
     acc /= reps
-    print(f"A={A} after {warm} steps: done {env.is_done.float().mean().item():.2f}; kernel span {np.mean([t[0] for t in total]):.0f} ticks, "
+    print(f"[{STEPS} steps per launch] A={A} after {warm} steps: done {env.is_done.float().mean().item():.2f}; kernel span {np.mean([t[0] for t in total]):.0f} ticks, "
           f"mean wave life {np.mean([t[1] for t in total]):.0f}, start skew {np.mean([t[2] for t in total]):.0f} (ticks = 100 MHz? see note)")
     for n, c in zip(names[1:], acc):
         print(f"   {n:24s} {c:9.0f}  {100 * c / acc.sum():5.1f} %")
