@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--min-episodes", type=int, default=8, help="... and span at least this many episodes")
     ap.add_argument("--max-repeats", type=int, default=4000)
     ap.add_argument("--per-step-launches", action="store_true", help="one launch per step instead of one per chunk (A/B)")
+    ap.add_argument("--lanes", type=int, choices=[0, 2, 4], default=0, help="lanes per table (A/B); 0 = the library's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--trainer-loop", choices=["auto", "on", "off"], default="auto", help="auto: at N = 1")
@@ -79,8 +80,20 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+_TYPES_CACHE = {}
+
+
 def native_types_for_episode(episode: int):
     """Seat -> PULSE_AGENT_* for this episode: Q seat = episode % 10, list rotated like get_rotated_agents."""
+    hit = _TYPES_CACHE.get(episode % 10)          # the rotation has period 10 (ten seats)
+    if hit is not None:
+        return hit
+    out = _native_types_for_episode(episode % 10)
+    _TYPES_CACHE[episode % 10] = out
+    return out
+
+
+def _native_types_for_episode(episode: int):
     from pulselib_amd.environments.Poker.utils import NATIVE_TYPE, PokerAgentType, get_rotated_agents
     names = ["qlearning"] + AGENTS
     types = [PokerAgentType(n) for n in names]
@@ -125,6 +138,19 @@ class EpisodeLoop:
     def run_steps(self, k, timer=None, time_every=0):
         """Run exactly k counted steps (episodes roll over inside)."""
         done = 0
+        native_loop = hasattr(self.env, "rollout_until") and getattr(self.rule, "handle", None) is not None and self.rule.exchange != "host"
+        while native_loop and done < k:
+            # the chunks of the episode and the rule's verdicts run in one native call (no interpreter per chunk)
+            n, over = self.env.rollout_until(self.native, self.actions, CHECK_INTERVAL, min(k - done, self.max_episode_steps - self.steps_in_episode),
+                                             self.global_step, self.rule, timer=timer, time_every=time_every)
+            self.calls += -(-n // CHECK_INTERVAL)
+            self.global_step += n
+            self.steps_in_episode += n
+            done += n
+            if over or self.steps_in_episode >= self.max_episode_steps:
+                if self.on_episode_end is not None:
+                    self.on_episode_end(self)
+                self.new_episode()
         while done < k:
             n = min(CHECK_INTERVAL, k - done, self.max_episode_steps - self.steps_in_episode)
             tm = timer if (timer is not None and time_every > 0 and self.calls % time_every == 0) else None
@@ -313,6 +339,7 @@ def main_rank(args):
     env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100,
                    max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=SEED, table_id0=rank * N)
     env.chunked_rollout = not args.per_step_launches
+    env.lanes_per_table = args.lanes or None
     rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world)
     stats = EpisodeStatsReducer(env, device, world)
     actions = torch.zeros(N, dtype=torch.long, device=device)
@@ -331,7 +358,7 @@ def main_rank(args):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ran = loop.run_steps(args.steps, timer=timer, time_every=4)
+        ran = loop.run_steps(args.steps, timer=timer, time_every=8)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0

@@ -62,6 +62,8 @@ enum {
 /* flags: kernel variants a caller (or a test) selects per view; 0 = the product defaults */
 #define PULSE_VIEW_NO_OBS_STAGING 0x1  /* store the observation column by column instead of LDS-staged 16-byte bursts  */
 #define PULSE_VIEW_NO_CHUNK       0x2  /* pulse_poker_rollout: one launch per step instead of one launch per chunk     */
+#define PULSE_VIEW_LANES2         0x4  /* two lanes per table in every launch  (default: 2 for a chunk, 4 for a step)  */
+#define PULSE_VIEW_LANES4         0x8  /* four lanes per table in every launch                                         */
 typedef struct PulsePokerView {
     int32_t n_games, n_players, active_players, max_players;   /* n_games <= 2^24 per view (shard larger batches) */
     int32_t obs_size, hand_ranks_len;
@@ -174,31 +176,56 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
                         float* rewards_even, float* rewards_odd, int32_t n_steps, void* timer, void* stoprule,
                         void* stream);
+/* The trainer's inner loop (scripts/Poker/trainGPU.py:79-108) for scripted tables, natively: roll-out chunks of
+ * chunk_steps (the reference's check interval, 5) are enqueued, each followed by the stop rule's verdict
+ * (pulse_stoprule_decide), until the rule ends the episode or max_steps steps have run -- no interpreter between the
+ * chunks.  *steps_done: steps executed (the caller's views / reward buffers have swapped roles if it is odd);
+ * *over: the rule fired.  timer + time_every > 0: every time_every-th chunk opens a HIP-event bracket over the next
+ * four chunks of the call (an event pair around every single launch costs the stream a fifth of the launch). */
+int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
+                              uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
+                              float* rewards_even, float* rewards_odd, int32_t chunk_steps, int32_t max_steps, void* timer,
+                              int32_t time_every, void* stoprule, void* stream, int32_t* steps_done, int32_t* over);
 int pulse_timer_create(void** timer);
 int pulse_timer_collect(void* timer, float* sum_ms, int32_t* n_launches, int64_t* n_steps);
 int pulse_timer_destroy(void* timer);
 
 /* The trainer's episode stop rule (scripts/Poker/trainGPU.py:27-33,99: every 5th step, more than `threshold` of the
  * tables done ends the episode) without its blocking read, for one GPU or for one process per GPU.
- * A "chunk" is one check point.  submit (or pulse_poker_rollout) counts the chunk's done tables in stream order; on
- * the handle's side stream the count is summed, all-reduced over the ranks when a communicator is attached (RCCL:
- * 8 bytes, off the step stream), and copied to pinned host memory.  decide() answers for the chunk submitted `lag`
- * chunks before the newest one -- a FIXED lag, so a run is reproducible and every rank of a job takes every
- * decision on the same chunk and ends every episode at the same step (equal collective sequences on all ranks).
- * lag 0 is the reference's blocking check; lag 1 (default of the host code) never waits in practice.
- * counts() returns the same chunk's local and global count (have = 0: no chunk of this episode is due yet); a host
- * that owns the cross-rank exchange itself (gloo) all-reduces `local`.  drain() marks an episode boundary: earlier
- * chunks decide nothing any more.  n_global = tables of the whole job (= n_local without a communicator).
- * The handle owns a side stream, 8 events, and < 1 MB of device / pinned memory, created on the current device. */
-int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, int32_t lag, void* comm, void** handle);
+ * A "check point" is one evaluation of the rule.  pulse_poker_rollout (or submit) leaves the check point's done
+ * tables counted per wavefront on the device; the NEXT launch on that stream sums them with one extra workgroup and
+ * writes the count + a sequence number into coherent pinned host memory, which decide()/counts() poll -- no event,
+ * no second stream, no kernel of its own between the steps' launches, and the host sees a count a microsecond after
+ * it exists.  decide() answers for the check point submitted `lag` check points before the newest one: a FIXED lag,
+ * so a run is reproducible and every rank of a job takes every decision on the same check point and ends every
+ * episode at the same step (equal collective sequences on all ranks).  lag 0 is the reference's blocking check (the
+ * count is then flushed by a kernel of its own); lag 1 (default of the host code) never waits in practice.
+ * Between the ranks of a job the counts are exchanged
+ *   - through a POSIX shared-memory segment (shm_name, rank, world: one cache line per rank and check point; the
+ *     ranks of one node; 8 bytes every 5 steps need no device), or
+ *   - by an RCCL all-reduce on a side stream of the rule (comm: a pulse_comm_create handle; an event hands each check
+ *     point over to that stream, which costs the steps' stream a barrier per check point), or
+ *   - by the caller: counts() returns the check point's local count, to be all-reduced by the host code (gloo).
+ * counts(): have = 0 while no check point of this episode is due.  drain() marks an episode boundary: earlier check
+ * points decide nothing any more.  n_global = tables of the whole job.  The handle owns < 1 MB of device / pinned
+ * memory (and, RCCL only, a stream and 8 events), created on the current device. */
+int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, int32_t lag, void* comm, const char* shm_name,
+                          int32_t rank, int32_t world, void** handle);
 int pulse_stoprule_submit(void* handle, const uint8_t* flags, int32_t n, void* stream);   /* flags: device uint8[n], != 0 = done */
 int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t* have);
 int pulse_stoprule_decide(void* handle, int32_t* over);
 int pulse_stoprule_drain(void* handle);
 int pulse_stoprule_destroy(void* handle);
 
-/* RCCL communicator of the job (one process per GPU), used for the stop rule's 8-byte all-reduce on its side
- * stream.  librccl is bound at run time (the copy PyTorch-ROCm loaded, else the system one), so the library loads
+/* The shared-memory exchange of the stop rule as an object of its own (host code only; the rule creates one itself when
+ * given shm_name).  Every rank maps the POSIX segment `name` (created by whoever comes first; unlink it once all ranks
+ * have it mapped) and calls all_sum with the same sequence of indices 0, 1, 2, ...: *total = sum of the ranks' values. */
+int pulse_shm_create(const char* name, int32_t rank, int32_t world, void** handle);
+int pulse_shm_all_sum(void* handle, int64_t index, int64_t value, int64_t* total);
+int pulse_shm_destroy(void* handle);
+
+/* RCCL communicator of the job (one process per GPU), for the stop rule's 8-byte all-reduce on its side
+ * stream (the `comm` exchange above).  librccl is bound at run time (the copy PyTorch-ROCm loaded, else the system one), so the library loads
  * without it.  unique_id: call on rank 0, hand the 128 bytes to every rank (torch.distributed broadcast), then
  * every rank calls create (collective).  all_reduce_i64: sum of int64[count], device pointers, in `stream` order. */
 int pulse_comm_unique_id(uint8_t* out128);

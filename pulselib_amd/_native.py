@@ -24,7 +24,7 @@ PH_FOLDWIN, PH_SHOWDOWN, PH_CLEARDONE, PH_REWARD, PH_OBS = 0x010, 0x020, 0x040, 
 PH_STEP = 0x1FF
 
 # PulsePokerView.flags: kernel variants selectable per view (include/pulse_env.h)
-VIEW_NO_OBS_STAGING, VIEW_NO_CHUNK = 0x1, 0x2
+VIEW_NO_OBS_STAGING, VIEW_NO_CHUNK, VIEW_LANES2, VIEW_LANES4 = 0x1, 0x2, 0x4, 0x8
 
 AGENT_EXTERNAL, AGENT_RANDOM, AGENT_HEURISTIC_HANDS, AGENT_TIGHT_AGGRESSIVE, AGENT_LOOSE_PASSIVE, AGENT_SMALL_BALL = range(6)
 
@@ -92,15 +92,19 @@ SYMBOLS = {
     "pulse_poker_policy": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _U64, _U64, _U64, _P, _P]),
     "pulse_poker_policy_step": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, _P]),
     "pulse_poker_rollout": (C.c_int, [_P, _P, _P, _U64, _U64, _U64, _P, _P, _P, _I32, _P, _P, _P]),
+    "pulse_poker_rollout_until": (C.c_int, [_P, _P, _P, _U64, _U64, _U64, _P, _P, _P, _I32, _I32, _P, _I32, _P, _P, _P, _P]),
     "pulse_timer_create": (C.c_int, [_P]),
     "pulse_timer_collect": (C.c_int, [_P, _P, _P, _P]),
     "pulse_timer_destroy": (C.c_int, [_P]),
-    "pulse_stoprule_create": (C.c_int, [_I32, _I64, C.c_double, _I32, _P, _P]),
+    "pulse_stoprule_create": (C.c_int, [_I32, _I64, C.c_double, _I32, _P, C.c_char_p, _I32, _I32, _P]),
     "pulse_stoprule_submit": (C.c_int, [_P, _P, _I32, _P]),
     "pulse_stoprule_counts": (C.c_int, [_P, _P, _P, _P]),
     "pulse_stoprule_decide": (C.c_int, [_P, _P]),
     "pulse_stoprule_drain": (C.c_int, [_P]),
     "pulse_stoprule_destroy": (C.c_int, [_P]),
+    "pulse_shm_create": (C.c_int, [C.c_char_p, _I32, _I32, _P]),
+    "pulse_shm_all_sum": (C.c_int, [_P, _I64, _I64, _P]),
+    "pulse_shm_destroy": (C.c_int, [_P]),
     "pulse_comm_unique_id": (C.c_int, [_P]),
     "pulse_comm_create": (C.c_int, [_P, _I32, _I32, _P]),
     "pulse_comm_all_reduce_i64": (C.c_int, [_P, _P, _P, _I32, _P]),

@@ -36,39 +36,60 @@ __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_
 // ------------------------------------------------------------------------------------ Blackjack
 __device__ __forceinline__ int bj_rank(int card) { const int r = card % 13 + 1; return r > 10 ? 10 : r; }
 
+// One lane per game.  The deck lives in the workgroup's LDS while it is shuffled (52 bytes per game: cards are 0..51)
+// and leaves as coalesced dwords -- consecutive lanes write consecutive words of the block's 256 x 52 deck region,
+// likewise for the two 256 x 20 card-row regions (a lane writing its own 52-word row strides 208 B between lanes:
+// 1.5 ms per 1 M games; this form is bound by the 0.4 GB it writes).
 __global__ __launch_bounds__(kBlock) void blackjack_reset_kernel(const PulseBlackjackView v, const int32_t* __restrict__ decks_src,
                                                                 int32_t* __restrict__ decks_out, uint64_t seed, uint64_t episode) {
-    const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= v.batch_size) return;
-    int32_t* d = decks_out + (size_t)g * 52;
-    if (decks_src) {
-        for (int c = 0; c < 52; ++c) d[c] = decks_src[(size_t)g * 52 + c];
-    } else {
-        // Fisher-Yates with Philox draws (replaces argsort(rand), blackjack.py:24-29)
-        for (int c = 0; c < 52; ++c) d[c] = c;
-        for (int i = 51, q = 0; i > 0; --i, ++q) {
-            const U4 r = philox4x32(seed, (uint64_t)g, episode * 16 + (uint64_t)(q >> 2));
-            const uint32_t w = (q & 3) == 0 ? r.x : (q & 3) == 1 ? r.y : (q & 3) == 2 ? r.z : r.w;
-            const int j = (int)__umulhi(w, (uint32_t)(i + 1));
-            const int tmp = d[i]; d[i] = d[j]; d[j] = tmp;
+    __shared__ uint8_t deck[kBlock][53];                 // 53: odd stride, a lane's swaps do not pile onto one LDS bank
+    __shared__ int32_t first[kBlock][4];                 // the four cards dealt at reset, as rank values (players 0/1, dealer 0/1)
+    const int g0 = blockIdx.x * kBlock, g = g0 + threadIdx.x;
+    const int in_block = min(kBlock, v.batch_size - g0);
+    uint8_t* d = deck[threadIdx.x];
+    const bool live = g < v.batch_size;
+    if (live) {
+        int c0, c1, c2, c3;                                  // the first four cards of the deck
+        if (decks_src) {                                     // injected decks are copied as they are (any int32), below
+            const int32_t* src = decks_src + (size_t)g * 52;
+            c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
+        } else {
+            // Fisher-Yates with Philox draws (replaces argsort(rand), blackjack.py:24-29)
+            for (int c = 0; c < 52; ++c) d[c] = (uint8_t)c;
+            for (int i = 51, q = 0; i > 0; --i, ++q) {
+                const U4 r = philox4x32(seed, (uint64_t)g, episode * 16 + (uint64_t)(q >> 2));
+                const uint32_t w = (q & 3) == 0 ? r.x : (q & 3) == 1 ? r.y : (q & 3) == 2 ? r.z : r.w;
+                const int j = (int)__umulhi(w, (uint32_t)(i + 1));
+                const uint8_t tmp = d[i]; d[i] = d[j]; d[j] = tmp;
+            }
+            c0 = d[0]; c1 = d[1]; c2 = d[2]; c3 = d[3];
         }
+        int r1 = bj_rank(c0); const bool a1 = r1 == 1; if (a1) r1 = 11;                   // :53-59
+        int d1 = bj_rank(c1); const bool da1 = d1 == 1; if (da1) d1 = 11;                 // :62-69
+        int r2 = bj_rank(c2); const bool a2 = r2 == 1; if (a2) r2 = 11;                   // :72-78
+        int d2 = bj_rank(c3); const bool dfirst = !da1 && d2 == 1; if (d2 == 1) d2 = 11;  // :81-87
+        first[threadIdx.x][0] = r1; first[threadIdx.x][1] = r2; first[threadIdx.x][2] = d1; first[threadIdx.x][3] = d2;
+        bool has = a1 || a2, dhas = da1 || dfirst;
+        int ps = r1 + r2, ds = d1 + d2;
+        if (ps > 21 && has) { ps -= 10; has = false; }                                    // :93-95
+        if (ds > 21 && dhas) { ds -= 10; dhas = false; }                                  // :99-101
+        v.players_card_idx[g] = 2; v.dealer_card_idx[g] = 2; v.deck_positions[g] = 4;
+        v.dealer_upcard[g] = d1; v.player_card_sums[g] = ps; v.dealer_card_sums[g] = ds;
+        v.has_ace[g] = has; v.dealer_has_ace[g] = dhas; v.terminated[g] = 0; v.rewards[g] = 0;
+        v.obs[g * 3 + 0] = ps; v.obs[g * 3 + 1] = has; v.obs[g * 3 + 2] = d1;
     }
-    int32_t* pc = v.players_cards + (size_t)g * 20;
-    int32_t* dc = v.dealer_cards + (size_t)g * 20;
-    for (int i = 0; i < 20; ++i) { pc[i] = 0; dc[i] = 0; }
-    int r1 = bj_rank(d[0]); const bool a1 = r1 == 1; if (a1) r1 = 11;                 // :53-59
-    int d1 = bj_rank(d[1]); const bool da1 = d1 == 1; if (da1) d1 = 11;               // :62-69
-    int r2 = bj_rank(d[2]); const bool a2 = r2 == 1; if (a2) r2 = 11;                 // :72-78
-    int d2 = bj_rank(d[3]); const bool dfirst = !da1 && d2 == 1; if (d2 == 1) d2 = 11; // :81-87
-    pc[0] = r1; pc[1] = r2; dc[0] = d1; dc[1] = d2;
-    bool has = a1 || a2, dhas = da1 || dfirst;
-    int ps = r1 + r2, ds = d1 + d2;
-    if (ps > 21 && has) { ps -= 10; has = false; }                                    // :93-95
-    if (ds > 21 && dhas) { ds -= 10; dhas = false; }                                  // :99-101
-    v.players_card_idx[g] = 2; v.dealer_card_idx[g] = 2; v.deck_positions[g] = 4;
-    v.dealer_upcard[g] = d1; v.player_card_sums[g] = ps; v.dealer_card_sums[g] = ds;
-    v.has_ace[g] = has; v.dealer_has_ace[g] = dhas; v.terminated[g] = 0; v.rewards[g] = 0;
-    v.obs[g * 3 + 0] = ps; v.obs[g * 3 + 1] = has; v.obs[g * 3 + 2] = d1;
+    __syncthreads();
+    // coalesced write-out of the block's regions
+    int32_t* dk = decks_out + (size_t)g0 * 52;
+    if (decks_src) { for (int i = threadIdx.x; i < in_block * 52; i += kBlock) dk[i] = decks_src[(size_t)g0 * 52 + i]; }
+    else { for (int i = threadIdx.x; i < in_block * 52; i += kBlock) dk[i] = deck[i / 52][i % 52]; }
+    int32_t* pc = v.players_cards + (size_t)g0 * 20;
+    int32_t* dc = v.dealer_cards + (size_t)g0 * 20;
+    for (int i = threadIdx.x; i < in_block * 20; i += kBlock) {
+        const int row = i / 20, c = i % 20;
+        pc[i] = c < 2 ? first[row][c] : 0;
+        dc[i] = c < 2 ? first[row][2 + c] : 0;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void blackjack_step_kernel(const PulseBlackjackView v, const int64_t* __restrict__ actions) {

@@ -90,38 +90,33 @@ __device__ __forceinline__ PolicyDraw policy_draw(const U4& call, uint64_t step)
 
 // ---------------------------------------------------------------- scripted opponents
 // environments/Poker/Player.py:79-176 + utils.py:121; c1,c2 = hole cards 1..52, pot = obs col 9.
+// Branch-free: the tables of a wavefront are played by different types, so a switch would run every case anyway
+// (and pay a branch for each).  Every type reduces to `raise ? base + randint(n) : otherwise`, one multiply for the draw.
 __device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot, const PolicyDraw& rnd) {
     const int r1 = pymod(c1, 13), r2 = pymod(c2, 13);
     const int d = r1 > r2 ? r1 - r2 : r2 - r1;
     const bool pair = r1 == r2;
-    int a = 0;
-    switch (type) {
-    case PULSE_AGENT_RANDOM:                                              // utils.py:121
-        a = rand_below(rnd.pick, 13); break;
-    case PULSE_AGENT_HEURISTIC_HANDS: {                                   // Player.py:85-102
-        const bool fold = r1 < 8 && r2 < 8;
-        const bool raise = (pair || r1 >= 10 || r2 >= 10) && !fold;
-        a = raise ? 2 + rand_below(rnd.pick, 9) : 0; break; }
-    case PULSE_AGENT_TIGHT_AGGRESSIVE: {                                  // Player.py:112-124
-        const bool fold = r1 < 7 && r2 < 7 && d > 5;
-        const bool raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
-        a = fold ? 0 : 1;
-        if (raise) a = 2 + 5 + rand_below(rnd.pick, 4);
-        break; }
-    case PULSE_AGENT_LOOSE_PASSIVE: {                                     // Player.py:134-149
-        const bool fold = r1 <= 4 && r2 <= 4 && d > 9;
-        const bool call = ((pair && r1 > 8) || (r1 >= 11 && r2 > 9) || (r2 >= 11 && r1 > 9)) && !fold;
-        const bool raise = rand_unit(rnd.coin) > 0.9f && call;
-        a = call ? 1 : 0;
-        if (raise) a = 2 + rand_below(rnd.pick, 4);
-        break; }
-    case PULSE_AGENT_SMALL_BALL: {                                        // Player.py:159-174
-        const bool fold = (r1 < 6 && r2 < 6 && pot > 30) || (r1 < 9 && r2 < 9 && pot > 80);
-        const bool raise = (pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5)) && !fold;
-        a = raise ? 2 + rand_below(rnd.pick, 3) : 0; break; }
-    default: break;
-    }
-    return a;
+    const bool strong = pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5);          // tight_aggressive / small_ball raise hands
+    // heuristic_hands (Player.py:85-102): fold (0) unless pair / a king or ace -> 2 + randint(0, 9)
+    const bool hh_fold = r1 < 8 && r2 < 8;
+    const bool hh_raise = (pair || r1 >= 10 || r2 >= 10) && !hh_fold;
+    // tight_aggressive (:112-124): call (1), fold small unconnected, raise 2 + randint(5, 9)
+    const bool ta_fold = r1 < 7 && r2 < 7 && d > 5;
+    const bool ta_raise = strong && !ta_fold;
+    // loose_passive (:134-149): fold (0), call (1) premium hands, of those rand() > .9 raises 2 + randint(0, 4)
+    const bool lp_fold = r1 <= 4 && r2 <= 4 && d > 9;
+    const bool lp_call = ((pair && r1 > 8) || (r1 >= 11 && r2 > 9) || (r2 >= 11 && r1 > 9)) && !lp_fold;
+    const bool lp_raise = rand_unit(rnd.coin) > 0.9f && lp_call;
+    // small_ball (:159-174): fold (0) weak hands into big pots, raise 2 + randint(0, 3)
+    const bool sb_fold = (r1 < 6 && r2 < 6 && pot > 30) || (r1 < 9 && r2 < 9 && pot > 80);
+    const bool sb_raise = strong && !sb_fold;
+    const bool t_rand = type == PULSE_AGENT_RANDOM, t_hh = type == PULSE_AGENT_HEURISTIC_HANDS, t_ta = type == PULSE_AGENT_TIGHT_AGGRESSIVE,
+               t_lp = type == PULSE_AGENT_LOOSE_PASSIVE, t_sb = type == PULSE_AGENT_SMALL_BALL;
+    const bool draws = t_rand || (t_hh && hh_raise) || (t_ta && ta_raise) || (t_lp && lp_raise) || (t_sb && sb_raise);
+    const int n = t_rand ? 13 : t_hh ? 9 : t_sb ? 3 : 4;                                 // randint range (utils.py:121: randint(0, 13))
+    const int base = t_rand ? 0 : t_ta ? 7 : 2;
+    const int otherwise = (t_ta && !ta_fold) || (t_lp && lp_call) ? 1 : 0;               // the type's action when it does not raise
+    return draws ? base + rand_below(rnd.pick, n) : otherwise;
 }
 
 // 32-bit byte-offset addressing: base pointers are wave-uniform (SGPR pair) and every array of a view is
@@ -170,6 +165,23 @@ PULSE_REDUCE(imin, int, PULSE_OP_MIN)
 PULSE_REDUCE(imax, int, PULSE_OP_MAX)
 PULSE_REDUCE(sum, int, PULSE_OP_ADD)
 #undef PULSE_REDUCE
+// reduction over the LPT adjacent lanes that own one table (LPT = 2: one quad-permute step, 4: two)
+template <int LPT> __device__ __forceinline__ uint32_t grp_or(uint32_t v) {
+    static_assert(LPT == 2 || LPT == 4, "lanes per table");
+    v |= (uint32_t)dpp_mov<kQuadXor1>((int)v);
+    if (LPT == 4) v |= (uint32_t)dpp_mov<kQuadXor2>((int)v);
+    return v;
+}
+template <int LPT> __device__ __forceinline__ int grp_imin(int v) {
+    v = min(v, dpp_mov<kQuadXor1>(v));
+    if (LPT == 4) v = min(v, dpp_mov<kQuadXor2>(v));
+    return v;
+}
+template <int LPT> __device__ __forceinline__ int grp_imax(int v) {
+    v = max(v, dpp_mov<kQuadXor1>(v));
+    if (LPT == 4) v = max(v, dpp_mov<kQuadXor2>(v));
+    return v;
+}
 
 // x mod A for x that is almost always within one period of [0, A): two conditional corrections,
 // integer division only on the (poked-state) slow path.
@@ -185,6 +197,29 @@ __device__ __forceinline__ int first_after_near(uint32_t bits, int x, int A) {
     if (!rot) return -1;
     const int seat = xm + 1 + (__ffs((int)rot) - 1);
     return seat >= A ? seat - A : seat;
+}
+
+// Sum a check point's partial done-counts (one workgroup) and publish {local, global = local, sequence number} into
+// coherent pinned host memory, the sequence number last behind a system-scope fence: the host polls it.  `host` =
+// nullptr: the device pair only.
+__device__ __forceinline__ void sum_and_publish(const uint32_t* __restrict__ partials, int n, long long* __restrict__ pair, long long* host, long long seq) {
+    long long s = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) s += partials[i];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    __shared__ long long w_[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) w_[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int k = 0; k < kBlock / 64; ++k) t += w_[k];
+        if (pair) { pair[0] = t; pair[1] = t; }
+        if (host) {
+            host[0] = t; host[1] = t;
+            __threadfence_system();
+            *reinterpret_cast<volatile long long*>(host + 2) = seq;
+            __threadfence_system();
+        }
+    }
 }
 
 }  // namespace pulse_dev

@@ -3,12 +3,14 @@
 //
 // Replaces the ~1,700 eager torch dispatches of one PokerGPU.step (environments/Poker/PokerGPU.py:527-633).
 //
-// Mapping: a table is owned by 4 adjacent lanes (one DPP quad), lane j owns seats j, j+4, j+8 (, j+12): 16 tables
-// per 64-wide wavefront, 64 per 256-thread workgroup.  Per-table scalars are replicated in the quad, so the scalar
-// part of the state machine costs 1/4 wave-instruction per table; per-seat rows ([N,P] int32, the reference's own
-// layout) are SPL unrolled dwords per lane.  Seat sets (ACTIVE seats, contenders, winners) are bitmasks OR-reduced
-// across the quad with DPP quad_perm modifiers (no LDS); "first ACTIVE seat after x" is a rotate + ffs on the mask;
-// side-pot layers are quad min/max butterflies.  All integer arithmetic is the reference's; the fp32 reward keeps
+// Mapping: a table is owned by LPT adjacent lanes (4 = one DPP quad, or 2), lane j owns seats j, j+LPT, j+2*LPT, ...
+// (SPL of them): 64/LPT tables per 64-wide wavefront.  Per-table scalars are replicated in the table's lanes, so the
+// scalar part of the state machine costs 1/LPT wave-instruction per table; per-seat rows ([N,P] int32, the reference's
+// own layout) are SPL unrolled dwords per lane.  Seat sets (ACTIVE seats, contenders, winners) are bitmasks OR-reduced
+// across the table's lanes with DPP quad_perm modifiers (no LDS); "first ACTIVE seat after x" is a rotate + ffs on the
+// mask; side-pot layers are min/max butterflies.  Four lanes per table give the single-step launch (bound by memory
+// latency) the most wavefronts in flight; two lanes halve the replicated scalar work of the chunk kernel, which is
+// bound by vector-instruction issue.  All integer arithmetic is the reference's; the fp32 reward keeps
 // torch's op order (no contraction; tanh rounded once from double).
 //
 // Memory: single step -- state is read once and only the words that changed are written back, in the reference's
@@ -22,16 +24,16 @@ using namespace pulse_dev;
 
 namespace {
 
-constexpr int LPT = 4;        // lanes per table (one DPP quad)
-
 // dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
 // (hole cards [16][P_][2], cache tags [16][P_], ranks [16][P_], street equities [16][3][P_], deck window [16][8]);
 // 16-byte aligned so that the observation block of the next wavefront is.
-__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats) { return (16 * obs_size + 16 * seats * 7 + 16 * 8 + 3) & ~3; }
+__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 7 + 8) + 3) & ~3; }
 
 struct PolicyArgs {
     uint64_t types_packed, seed, step_counter, table_id0;
     uint32_t* wave_done;                   // nullptr, or one word per wavefront of the launch: tables done after the last step
+    // the PREVIOUS check point's wavefront counts, summed and published to the host by one extra workgroup of this launch
+    const uint32_t* carry_partials; int carry_n; long long* carry_host; long long carry_seq;
 };
 struct ChunkArgs {                         // MULTI only: the odd steps' output buffers and the number of steps
     float* obs_odd;
@@ -65,17 +67,23 @@ __device__ __forceinline__ float tanh_rn(float x) {
 // workgroup barrier is involved.
 // MULTI: ca.n_steps steps in one launch (fused policy only); step i writes observation / done flag / reward into
 // the even (i even) or odd buffers, as n single launches on the two ping-pong views would.
-template <uint32_t PH, bool POLICY, int SPL, bool WOBS, bool MULTI>
-__global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
+template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, bool MULTI>
+__global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
                                                            const int32_t* __restrict__ actor_idx_in,
                                                            float* __restrict__ rewards, const PolicyArgs pa, const ChunkArgs ca) {
-    static_assert(SPL == 3 || SPL == 4, "seats per lane: 3 (<= 12 seats) or 4 (<= 16)");
+    static_assert((LPT == 4 && (SPL == 3 || SPL == 4)) || (LPT == 2 && (SPL == 5 || SPL == 8)), "lanes per table x seats per lane: 4x3, 4x4, 2x5, 2x8");
+    constexpr int TPW = 64 / LPT;                                        // tables per wavefront
     static_assert(!MULTI || (POLICY && PH == PULSE_PH_STEP), "a chunk is fused policy + full step");
     extern __shared__ int4 smem4[];
+    if (POLICY && pa.carry_n > 0 && blockIdx.x == gridDim.x - 1) {       // the extra workgroup: the stop rule's previous check point
+        sum_and_publish(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
+        return;
+    }
     const int gt = blockIdx.x * kBlock + threadIdx.x;
     const int t = gt / LPT;
-    const int j = gt % LPT;
-    if (t >= v.n_games) return;   // whole quads leave together
+    const int j_lane = gt % LPT;
+    const int j = j_lane;
+    if (t >= v.n_games) return;   // the lanes of a table leave together
     STAMP(0);
     const int P = v.n_players, A = v.active_players;
     const int32_t* __restrict__ hr = v.hand_ranks;
@@ -110,14 +118,15 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
     // are staged in the wavefront's LDS slice ONCE.  A global load inside the step loop would have to be waited for
     // with s_waitcnt vmcnt, which counts stores too -- i.e. for every observation / reward / done store of the
     // previous step (the profile showed wavefronts parked there half of their life); LDS reads wait for nothing.
-    constexpr int P_ = LPT * SPL;                                       // seats per table as staged (12 or 16)
-    const int wave = threadIdx.x >> 6, q = (threadIdx.x & 63) >> 2;      // wavefront of the workgroup, table of the wavefront
-    int32_t* const lw = reinterpret_cast<int32_t*>(smem4) + wave * chunk_lds_dwords(v.obs_size, P_);
-    int32_t* const l_hands = lw + 16 * v.obs_size;                       // [16][P_][2]
-    int32_t* const l_prehands = l_hands + 16 * P_ * 2;                   // [16][P_]
-    int32_t* const l_prerank = l_prehands + 16 * P_;                     // [16][P_]
-    float* const l_preeq = reinterpret_cast<float*>(l_prerank + 16 * P_);   // [16][3][P_]
-    int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + 16 * 3 * P_);   // [16][8]: cards at deck position dpos0 + 0..7
+    constexpr int P_ = LPT * SPL;                                       // seats per table as staged (10, 12 or 16)
+    const int wave = threadIdx.x >> 6, q = (threadIdx.x & 63) / LPT;     // wavefront of the workgroup, table of the wavefront
+    int32_t* const lw = reinterpret_cast<int32_t*>(smem4) + wave * chunk_lds_dwords(v.obs_size, P_, TPW);
+    int32_t* const l_hands = lw + TPW * v.obs_size;                      // [TPW][P_][2]
+    int32_t* const l_prehands = l_hands + TPW * P_ * 2;                  // [TPW][P_]
+    int32_t* const l_prerank = l_prehands + TPW * P_;                    // [TPW][P_]
+    float* const l_preeq = reinterpret_cast<float*>(l_prerank + TPW * P_);  // [TPW][3][P_]
+    int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + TPW * 3 * P_);  // [TPW][8]: cards at deck position dpos0 + 0..7
+    constexpr int DPL = 8 / LPT;                                         // deck-window entries each lane stages
     const int dpos0 = dpos;
     const bool cache_on = (PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board;
     if (MULTI) {
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
         }
         const int32_t* dk = v.decks + (size_t)t * 52;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int at = dpos0 + 2 * j + e;
-            l_deck[q * 8 + 2 * j + e] = (uint32_t)at < 52u ? dk[at] : 0;
+        for (int e = 0; e < DPL; ++e) {
+            const int at = dpos0 + DPL * j + e;
+            l_deck[q * 8 + DPL * j + e] = (uint32_t)at < 52u ? dk[at] : 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -159,13 +168,15 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
     int dwin0 = dpos0;
     auto deck_card = [&](int at) -> int {
         if (!MULTI) return (uint32_t)at < 52u ? v.decks[(size_t)t * 52 + at] : 0;
-        if ((uint32_t)(at - dwin0) >= 8u) {                         // table-uniform: the four lanes compute the same `at`
+        if ((uint32_t)(at - dwin0) >= 8u) {                         // table-uniform: the table's lanes compute the same `at`
             dwin0 = at;
             const int32_t* dk = v.decks + (size_t)t * 52;
-            const int a0 = at + 2 * j, a1 = at + 2 * j + 1;
-            const int c0 = (uint32_t)a0 < 52u ? dk[a0] : 0, c1 = (uint32_t)a1 < 52u ? dk[a1] : 0;
+            int c[DPL];
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) { const int a = at + DPL * j + e; c[e] = (uint32_t)a < 52u ? dk[a] : 0; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            l_deck[q * 8 + 2 * j] = c0; l_deck[q * 8 + 2 * j + 1] = c1;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) l_deck[q * 8 + DPL * j + e] = c[e];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
     long long act64 = 0;
     if ((PH & (PULSE_PH_EXECUTE | PULSE_PH_REWARD)) && actions) act64 = ldo(actions, ut * 8u);
     // the Philox draws depend on no load: issue them now, they execute under the load latency.  In a chunk lane j
-    // of the quad computes call (first + j): four calls = eight steps of draws in the time of one.
+    // of the table computes call (first + j): LPT calls = 2 * LPT steps of draws in the time of one.
     const uint64_t tid = pa.table_id0 + (uint64_t)t;
     uint64_t pool_base = pa.step_counter >> 1;
     U4 pool{0, 0, 0, 0};
@@ -195,8 +206,8 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
     int prev_stack = 0, prev_invested = 0;
 
     // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
-#define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return quad_or(m_); }())
-#define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)quad_or(r_); }())
+#define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return grp_or<LPT>(m_); }())
+#define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)grp_or<LPT>(r_); }())
 
     STAMP(1);   // loads issued
     // The seat to act, as every lane of the table sees it: status / stack / round bet / hole cards.  Nothing changes
@@ -216,6 +227,11 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
     uint8_t* done_dst = v.is_done_out; uint8_t* done_nxt = v.is_done;
     float* rew_dst = rewards; float* rew_nxt = MULTI ? ca.rewards_odd : rewards;
     for (int i = 0; i < n_steps; ++i) {
+        // In a chunk, everything derived from the lane's position in its table (seat numbers, `seat < A` masks, ...)
+        // is re-derived inside the step: hoisted out of the loop those lane masks filled the scalar registers and were
+        // spilled (~200 v_readlane per step to fetch them back); a compare is cheaper than its reload.
+        int j = j_lane;
+        if (MULTI) asm volatile("" : "+v"(j));
 
         // ---- capture (PokerGPU.py:530-539)
         const bool prev_done = done;
@@ -242,8 +258,8 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                 }
                 const int rel = (int)(call - pool_base);
                 const PolicyDraw mine = policy_draw(pool, step);
-                draw.pick = quad_or(j == rel ? mine.pick : 0u);
-                draw.coin = quad_or(j == rel ? mine.coin : 0u);
+                draw.pick = grp_or<LPT>(j == rel ? mine.pick : 0u);
+                draw.coin = grp_or<LPT>(j == rel ? mine.coin : 0u);
             } else {
                 draw = policy_draw(pool, step);
             }
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
             uint32_t r_ = 0;
 #pragma unroll
             for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == actor ? __float_as_uint(eq[k]) : 0u;
-            e_actor = __uint_as_float(quad_or(r_));
+            e_actor = __uint_as_float(grp_or<LPT>(r_));
             if (actor >= LPT * SPL) e_actor = 0.5f;
         }
 
@@ -432,13 +448,13 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                     int lv = INT_MAX;
 #pragma unroll
                     for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] > prev_level) lv = min(lv, inv[k]);
-                    const int level = quad_imin(lv);
+                    const int level = grp_imin<LPT>(lv);
                     if (level == INT_MAX) break;
                     const int n_contrib = __popc(SEAT_BITS((j + LPT * k) < A && inv[k] >= level));
                     int bl = INT_MIN;
 #pragma unroll
                     for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] >= level && eligible[k]) bl = max(bl, rank[k]);
-                    const int best = quad_imax(bl);
+                    const int best = grp_imax<LPT>(bl);
                     const uint32_t win_bits = SEAT_BITS((j + LPT * k) < A && inv[k] >= level && eligible[k] && rank[k] == best);
                     const int n_win = __popc(win_bits);
                     if (n_win > 0) {
@@ -489,8 +505,8 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
         // ---- 6) observation for the next seat to act (PokerGPU.py:159-179)
         if (PH & PULSE_PH_OBS) {
             const int wlane = threadIdx.x & 63;
-            float* const l_obs = MULTI ? reinterpret_cast<float*>(lw) : reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * 16 * v.obs_size;
-            float* __restrict__ o = WOBS ? l_obs + (wlane >> 2) * v.obs_size
+            float* const l_obs = MULTI ? reinterpret_cast<float*>(lw) : reinterpret_cast<float*>(smem4) + (threadIdx.x >> 6) * TPW * v.obs_size;
+            float* __restrict__ o = WOBS ? l_obs + q * v.obs_size
                                          : reinterpret_cast<float*>(reinterpret_cast<char*>(obs_dst) + __umul24(ut, (uint32_t)v.obs_size) * 4u);
             const int seat_i = idx & 15;
             const int n_h0 = MULTI ? next_hand.x : SEAT_PICK(h0, seat_i), n_h1 = MULTI ? next_hand.y : SEAT_PICK(h1, seat_i);
@@ -498,12 +514,15 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
             if (MULTI) { a_status = n_status; a_stack = n_stack; a_bet = n_bet; a_h0 = n_h0; a_h1 = n_h1; }   // the next step's actor
             const int idxm = mod_near(idx, A);
             const int pos = mod_near(idx - button, A);
-            // columns 0..12, four per quad pass: lane j writes column 4*pass + j (a 4-way select per pass)
-            const int h0v = j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
-            const int h1v = j == 0 ? b4 : j == 1 ? n_h0 : j == 2 ? n_h1 : stage;
-            const int h2v = j == 0 ? pos : j == 1 ? pot : j == 2 ? highest - n_bet : n_stack;
-            o[j] = (float)h0v; o[4 + j] = (float)h1v; o[8 + j] = (float)h2v;
-            if (j == 0) o[12] = (float)n_status;
+            // columns 0..12, LPT per pass: lane j writes column LPT*pass + j (an LPT-way select per pass)
+            const int col[13] = {b0, b1, b2, b3, b4, n_h0, n_h1, stage, pos, pot, highest - n_bet, n_stack, n_status};
+#pragma unroll
+            for (int c0 = 0; c0 < 13; c0 += LPT) {
+                int hv = col[c0];
+#pragma unroll
+                for (int jj = 1; jj < LPT; ++jj) if (c0 + jj < 13 && j == jj) hv = col[c0 + jj];
+                if (c0 + j < 13) o[c0 + j] = (float)hv;
+            }
             // opponents: seat (idx+1+k)%A -> columns 13+3k..; seats >= A zero-fill the padding slots
 #pragma unroll
             for (int k = 0; k < SPL; ++k) {
@@ -520,11 +539,19 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int n4 = 4 * v.obs_size;                                   // int4 per wavefront block
-                const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) << 4;   // first table of this wavefront
+                const int n4 = TPW / 4 * v.obs_size;                             // int4 per wavefront block
+                const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
                 const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
                 const int4* src = reinterpret_cast<const int4*>(l_obs);
-                for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
+                constexpr int UB = LPT == 4 ? 1 : 5;                             // LDS reads issued together, then the stores: one round trip
+                for (int e0 = wlane; e0 < n4; e0 += 64 * UB) {
+                    int4 piece[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) if (e0 + 64 * u < n4) piece[u] = src[e0 + 64 * u];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+                        if (e0 + 64 * u < n4) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)(e0 + 64 * u) * 16u, piece[u]);
+                }
                 if (MULTI) {       // the next step's values must not overtake these reads of the slice
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -564,8 +591,14 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
     }
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
         if (board_dirty) {
-            sto(vs.board, bo + (uint32_t)j * 4u, j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3);
-            if (j == 0) sto(vs.board, bo + 16u, b4);
+            const int bd[5] = {b0, b1, b2, b3, b4};
+#pragma unroll
+            for (int c0 = 0; c0 < 5; c0 += LPT) {
+                int cv = bd[c0];
+#pragma unroll
+                for (int jj = 1; jj < LPT; ++jj) if (c0 + jj < 5 && j == jj) cv = bd[c0 + jj];
+                if (c0 + j < 5) sto(vs.board, bo + (uint32_t)(c0 + j) * 4u, cv);
+            }
         }
     }
     if (j == 0) {
@@ -599,45 +632,67 @@ __global__ __launch_bounds__(kBlock, 4) void poker_step_kernel(const PulsePokerV
 }
 
 // ---------------------------------------------------------------- host side
-inline dim3 step_grid(const PulsePokerView& v) { return dim3((unsigned)(((long long)v.n_games * LPT + kBlock - 1) / kBlock)); }
-inline int seats_per_lane(const PulsePokerView& v) { return (v.max_players + LPT - 1) / LPT; }   // covers max_players (obs padding too)
-inline bool obs_staging(const PulsePokerView& v, const float* obs_odd) {
-    return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games & 15) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
+// lanes per table of a launch: the view's flags can force it (tests, A/B timing); otherwise four for a single step
+// (memory-latency-bound: more wavefronts in flight) and two for a chunk (issue-bound: less replicated scalar work)
+inline int lanes_for(const PulsePokerView& v, bool chunk) {
+    if (v.flags & PULSE_VIEW_LANES2) return 2;
+    if (v.flags & PULSE_VIEW_LANES4) return 4;
+    return chunk ? 2 : 4;
 }
-inline size_t obs_lds(const PulsePokerView& v) { return sizeof(float) * (size_t)(kBlock / 64) * 16 * (size_t)v.obs_size; }
+inline dim3 step_grid(const PulsePokerView& v, int lpt) { return dim3((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)); }
+inline bool obs_staging(const PulsePokerView& v, const float* obs_odd, int lpt) {
+    return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games % (64 / lpt)) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
+}
+
+template <uint32_t PH, bool POLICY, int LPT, int SPL, bool MULTI>
+void launch_one(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, const ChunkArgs& ca,
+                hipStream_t st) {
+    dim3 grid = step_grid(v, LPT);
+    const dim3 block(kBlock);
+    if (POLICY && pa.carry_n > 0) grid.x += 1;       // + the workgroup that publishes the stop rule's previous check point
+    constexpr int TPW = 64 / LPT;
+    const bool wobs = (PH & PULSE_PH_OBS) && (MULTI || PH == PULSE_PH_STEP) && obs_staging(v, MULTI ? ca.obs_odd : nullptr, LPT);
+    const size_t lds = MULTI ? sizeof(int32_t) * (size_t)(kBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, LPT * SPL, TPW)
+                             : (wobs ? sizeof(float) * (size_t)(kBlock / 64) * TPW * (size_t)v.obs_size : 0);
+    constexpr bool W = PH == PULSE_PH_STEP;          // only the full step is instantiated with observation staging
+    if (lds > 48 * 1024) {                           // beyond the default dynamic-LDS limit: raise it (to what this launch needs)
+        static size_t raised[2] = {0, 0};
+        if (raised[wobs ? 1 : 0] < lds) {
+            const void* fn = wobs ? reinterpret_cast<const void*>(&poker_step_kernel<PH, POLICY, LPT, SPL, W, MULTI>)
+                                  : reinterpret_cast<const void*>(&poker_step_kernel<PH, POLICY, LPT, SPL, false, MULTI>);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised[wobs ? 1 : 0] = lds;
+            else (void)hipGetLastError();            // the launch below reports what is wrong, not this call's sticky error
+        }
+    }
+    if (wobs) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, LPT, SPL, W, MULTI>), grid, block, lds, st, v, actions, actor_idx, rewards, pa, ca);
+    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, LPT, SPL, false, MULTI>), grid, block, lds, st, v, actions, actor_idx, rewards, pa, ca);
+}
+
+template <uint32_t PH, bool POLICY, bool MULTI>
+void launch_any(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, const ChunkArgs& ca,
+                hipStream_t st) {
+    // seats per lane must cover max_players (the observation's padding slots too)
+    if (lanes_for(v, MULTI) == 2) {
+        if (v.max_players <= 10) launch_one<PH, POLICY, 2, 5, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
+        else launch_one<PH, POLICY, 2, 8, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
+    } else {
+        if (v.max_players <= 12) launch_one<PH, POLICY, 4, 3, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
+        else launch_one<PH, POLICY, 4, 4, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
+    }
+}
 
 template <uint32_t PH, bool POLICY>
-void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa,
-                 hipStream_t st) {
-    const dim3 grid = step_grid(v), block(kBlock);
-    const ChunkArgs ca{nullptr, nullptr, 1};
-    const bool three = seats_per_lane(v) <= 3;
-    if (PH == PULSE_PH_STEP && obs_staging(v, nullptr)) {
-        constexpr bool W = PH == PULSE_PH_STEP;
-        if (three) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 3, W, false>), grid, block, obs_lds(v), st, v, actions, actor_idx, rewards, pa, ca);
-        else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, W, false>), grid, block, obs_lds(v), st, v, actions, actor_idx, rewards, pa, ca);
-    }
-    else if (three) hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 3, false, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa, ca);
-    else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, 4, false, false>), grid, block, 0, st, v, actions, actor_idx, rewards, pa, ca);
+void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, hipStream_t st) {
+    launch_any<PH, POLICY, false>(v, actions, actor_idx, rewards, pa, ChunkArgs{nullptr, nullptr, 1}, st);
 }
 
 void launch_chunk(const PulsePokerView& v, int64_t* actions, float* rewards_even, const PolicyArgs& pa, const ChunkArgs& ca, hipStream_t st) {
-    const dim3 grid = step_grid(v), block(kBlock);
-    const bool three = seats_per_lane(v) <= 3;
-    constexpr uint32_t PH = PULSE_PH_STEP;
-    const int32_t* no_actor = nullptr;
-    const size_t lds = sizeof(int32_t) * (size_t)(kBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, three ? 12 : 16);
-    if (obs_staging(v, ca.obs_odd)) {
-        if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, true, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
-        else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, true, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
-    }
-    else if (three) hipLaunchKernelGGL((poker_step_kernel<PH, true, 3, false, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
-    else hipLaunchKernelGGL((poker_step_kernel<PH, true, 4, false, true>), grid, block, lds, st, v, actions, no_actor, rewards_even, pa, ca);
+    launch_any<PULSE_PH_STEP, true, true>(v, actions, nullptr, rewards_even, pa, ca, st);
 }
 
 template <uint32_t PH>
 void launch_phase(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, hipStream_t st) {
-    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0, nullptr}, st);
+    launch_step<PH, false>(v, actions, actor_idx, rewards, PolicyArgs{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0}, st);
 }
 
 }  // namespace
@@ -648,7 +703,31 @@ struct PulseTimer {
     hipEvent_t start[kMax], stop[kMax];
     int launches[kMax], steps[kMax];
     int created = 0, used = 0;
+    long long calls = 0;                  // chunks seen by pulse_poker_rollout_until (a bracket opens every time_every-th)
+    bool open = false;                    // a bracket is open: start recorded, stop not yet
+    int open_launches = 0, open_steps = 0;
 };
+
+namespace {
+constexpr int kTimedSpan = 4;             // consecutive chunks per event pair: the pair's own queue time (~a fifth of a chunk) is shared by four
+int timer_begin(PulseTimer* tm, hipStream_t st) {
+    if (tm->used >= PulseTimer::kMax) return 0;
+    if (tm->used >= tm->created) {
+        if (hipEventCreate(&tm->start[tm->created]) != hipSuccess || hipEventCreate(&tm->stop[tm->created]) != hipSuccess)
+            return pulse::fail(PULSE_ENODEVICE, "roll-out timer: hipEventCreate failed");
+        ++tm->created;
+    }
+    const hipError_t e = hipEventRecord(tm->start[tm->used], st);
+    if (e != hipSuccess) return pulse::fail_hip((int)e, "roll-out timer: hipEventRecord");
+    tm->open = true; tm->open_launches = 0; tm->open_steps = 0;
+    return 0;
+}
+void timer_end(PulseTimer* tm, hipStream_t st) {
+    (void)hipEventRecord(tm->stop[tm->used], st);
+    tm->launches[tm->used] = tm->open_launches; tm->steps[tm->used] = tm->open_steps; ++tm->used;
+    tm->open = false;
+}
+}  // namespace
 
 extern "C" {
 
@@ -665,7 +744,7 @@ int pulse_poker_policy_step(const PulsePokerView* v, const uint8_t* agent_types,
     if (int rc = pulse::check_view(v, "pulse_poker_policy_step")) return rc;
     if (!actions || !rewards || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_policy_step: null argument");
     if (v->n_games == 0) return 0;
-    const PolicyArgs pa{pulse::pack_types(agent_types, v->n_players), seed, step_counter, table_id0, nullptr};
+    const PolicyArgs pa{pulse::pack_types(agent_types, v->n_players), seed, step_counter, table_id0, nullptr, nullptr, 0, nullptr, 0};
     launch_step<PULSE_PH_STEP, true>(*v, actions, nullptr, rewards, pa, (hipStream_t)stream);
     return pulse::finish_launch("pulse_poker_policy_step");
 }
@@ -701,11 +780,12 @@ int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* 
 int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* actions, float* rewards, uint64_t types_packed,
                        uint64_t step_counter, void* stream) {
     if (int rc = pulse::check_view(v, "pulse_poker_ablate")) return rc;
-    const dim3 grid = step_grid(*v), block(kBlock);
-    const PolicyArgs pa{types_packed, 1, step_counter, 0, nullptr};
+    if (v->max_players > 12) return pulse::fail(PULSE_EINVAL, "pulse_poker_ablate: max_players <= 12");
+    const dim3 grid = step_grid(*v, 4), block(kBlock);
+    const PolicyArgs pa{types_packed, 1, step_counter, 0, nullptr, nullptr, 0, nullptr, 0};
     const ChunkArgs ca{nullptr, nullptr, 1};
     hipStream_t st = (hipStream_t)stream;
-#define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 3, false, false>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa, ca); break;
+#define PULSE_ABL(MASK) case (MASK): hipLaunchKernelGGL((poker_step_kernel<(MASK), true, 4, 3, false, false>), grid, block, 0, st, *v, actions, (const int32_t*)nullptr, rewards, pa, ca); break;
     switch (phases) {
     PULSE_ABL(PULSE_PH_STEP)
     PULSE_ABL(PULSE_PH_STEP & ~PULSE_PH_EQUITY)
@@ -773,37 +853,59 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     const uint64_t packed = pulse::pack_types(agent_types, v_even->n_players);
     const bool chunk = !(v_even->flags & PULSE_VIEW_NO_CHUNK);
     PulseTimer* tm = static_cast<PulseTimer*>(timer);
-    const bool timed = tm && tm->used < PulseTimer::kMax;
-    if (timed) {
-        if (tm->used >= tm->created) {
-            if (hipEventCreate(&tm->start[tm->created]) != hipSuccess || hipEventCreate(&tm->stop[tm->created]) != hipSuccess)
-                return pulse::fail(PULSE_ENODEVICE, "pulse_poker_rollout: hipEventCreate failed");
-            ++tm->created;
-        }
-        const hipError_t e = hipEventRecord(tm->start[tm->used], st);
-        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_poker_rollout: hipEventRecord");
-    }
+    const bool timed = tm && !tm->open && tm->used < PulseTimer::kMax;
+    if (timed) if (int rc = timer_begin(tm, st)) return rc;
     PulseStopRule* rule = static_cast<PulseStopRule*>(stoprule);
-    const int n_waves = (int)(((long long)v_even->n_games * LPT + 63) / 64);
+    const int n_waves = (int)(((long long)v_even->n_games * lanes_for(*v_even, chunk) + 63) / 64);
     uint32_t* wave_done = nullptr;
-    if (rule) if (int rc = pulse::stoprule_claim(rule, n_waves, &wave_done)) return rc;   // the slot must be free before the last launch writes into it
+    pulse::StopRuleCarry carry{nullptr, 0, nullptr, 0};
+    if (rule) if (int rc = pulse::stoprule_claim(rule, n_waves, &wave_done, &carry)) return rc;
     if (chunk) {
-        const PolicyArgs pa{packed, seed, step_counter0, table_id0, wave_done};
+        const PolicyArgs pa{packed, seed, step_counter0, table_id0, wave_done, carry.partials, carry.n, carry.host, carry.seq};
         launch_chunk(*v_even, actions, rewards_even, pa, ChunkArgs{v_odd->obs, rewards_odd, n_steps}, st);
     } else {
         for (int i = 0; i < n_steps; ++i) {
             const PulsePokerView& v = (i & 1) ? *v_odd : *v_even;
             float* rw = (i & 1) ? rewards_odd : rewards_even;
-            const PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0, i == n_steps - 1 ? wave_done : nullptr};
+            PolicyArgs pa{packed, seed, step_counter0 + (uint64_t)i, table_id0, i == n_steps - 1 ? wave_done : nullptr, nullptr, 0, nullptr, 0};
+            if (i == 0) { pa.carry_partials = carry.partials; pa.carry_n = carry.n; pa.carry_host = carry.host; pa.carry_seq = carry.seq; }
             launch_step<PULSE_PH_STEP, true>(v, actions, nullptr, rw, pa, st);
         }
     }
-    if (timed) {
-        (void)hipEventRecord(tm->stop[tm->used], st);
-        tm->launches[tm->used] = chunk ? 1 : n_steps; tm->steps[tm->used] = n_steps; ++tm->used;
-    }
+    if (timed) { tm->open_launches = chunk ? 1 : n_steps; tm->open_steps = n_steps; timer_end(tm, st); }
     if (int rc = pulse::finish_launch("pulse_poker_rollout")) return rc;
     if (rule) return pulse::stoprule_commit(rule, n_waves, st);
+    return 0;
+}
+
+int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
+                              uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions, float* rewards_even,
+                              float* rewards_odd, int32_t chunk_steps, int32_t max_steps, void* timer, int32_t time_every,
+                              void* stoprule, void* stream, int32_t* steps_done, int32_t* over) {
+    if (!steps_done || !over || chunk_steps <= 0 || max_steps < 0 || !stoprule)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout_until: bad argument");
+    PulseTimer* tm = static_cast<PulseTimer*>(timer);
+    hipStream_t st = (hipStream_t)stream;
+    const bool per_step = (v_even->flags & PULSE_VIEW_NO_CHUNK) != 0;
+    int done = 0, parity = 0, verdict = 0;
+    while (done < max_steps && !verdict) {
+        const int n = chunk_steps < max_steps - done ? chunk_steps : max_steps - done;
+        // an event pair brackets kTimedSpan consecutive chunks, every time_every-th chunk opens one
+        if (tm && time_every > 0 && !tm->open && (tm->calls % time_every) == 0) if (int rc = timer_begin(tm, st)) return rc;
+        if (tm) ++tm->calls;
+        // after an odd number of steps the roles of the two views (and reward buffers) are swapped
+        if (int rc = pulse_poker_rollout(parity ? v_odd : v_even, parity ? v_even : v_odd, agent_types, seed, step_counter0 + (uint64_t)done,
+                                         table_id0, actions, parity ? rewards_odd : rewards_even, parity ? rewards_even : rewards_odd, n,
+                                         nullptr, stoprule, stream)) return rc;
+        done += n; parity ^= n & 1;
+        if (tm && tm->open) {
+            tm->open_launches += per_step ? n : 1; tm->open_steps += n;
+            if (tm->open_launches >= (per_step ? kTimedSpan * chunk_steps : kTimedSpan)) timer_end(tm, st);
+        }
+        if (int rc = pulse_stoprule_decide(stoprule, &verdict)) return rc;
+    }
+    if (tm && tm->open) timer_end(tm, st);            // the episode ended inside a bracket: it covers what ran
+    *steps_done = done; *over = verdict;
     return 0;
 }
 

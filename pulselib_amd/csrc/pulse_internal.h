@@ -13,9 +13,17 @@ namespace pulse {
 int fail(int code, const char* msg);
 int fail_hip(int hip_error, const char* what);
 
-// stoprule.hip: a chunk's partial done-counts (one uint32 per wavefront / workgroup) are written in stream order
-// into the slot `claim` hands out; `commit` sums, all-reduces and copies them to the host on the rule's side stream.
-int stoprule_claim(PulseStopRule* h, int n_partials, uint32_t** partials_out);
+// stoprule.hip: a check point's partial done-counts (one uint32 per wavefront / workgroup) are written in stream order
+// into the slot `claim` hands out.  Their sum is published to the host by the NEXT launch on that stream: `claim` also
+// returns the previous check point's counts as a `carry`, which that launch sums and publishes with one extra
+// workgroup (no event, no second stream, no kernel of its own on the steps' stream).
+struct StopRuleCarry {
+    const uint32_t* partials;     // nullptr: nothing to carry
+    int n;
+    long long* host;              // {local, global, seq} in coherent pinned memory
+    long long seq;
+};
+int stoprule_claim(PulseStopRule* h, int n_partials, uint32_t** partials_out, StopRuleCarry* carry);
 int stoprule_commit(PulseStopRule* h, int n_partials, ihipStream_t* stream);
 
 }  // namespace pulse

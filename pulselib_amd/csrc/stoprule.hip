@@ -10,7 +10,11 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -104,18 +108,25 @@ int pulse_comm_destroy(void* comm) {
 
 // ---------------------------------------------------------------- the rule
 namespace {
-constexpr int kSlots = 4;                 // chunks in flight: lag < kSlots
+constexpr int kSlots = 4;                 // check points in flight: lag < kSlots
 constexpr int kMaxPartials = 1024;        // workgroups of the flag-counting kernel
 
-// partial counts of one chunk -> {local, local} (pair[1] is overwritten by the all-reduce when there is one)
-__global__ __launch_bounds__(kBlock) void stoprule_sum_kernel(const uint32_t* __restrict__ partials, int n, long long* __restrict__ pair) {
-    long long s = 0;
-    for (int i = threadIdx.x; i < n; i += kBlock) s += partials[i];
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    __shared__ long long w[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { long long t = 0; for (int k = 0; k < kBlock / 64; ++k) t += w[k]; pair[0] = t; pair[1] = t; }
+// What the host polls, in coherent pinned memory: the counts of one check point, then its sequence number (written
+// last, behind a system-scope fence) -- the host learns of a result a microsecond after the kernel wrote it, without
+// an event wait's wake-up (tens of microseconds).
+struct Published { long long local, global, seq, pad; };
+
+// sum + publish as a kernel of its own: the flush of a check point no later launch will carry (lag 0, the trainer's
+// flag counts), and the first half of the RCCL path (host == nullptr: the device pair only)
+__global__ __launch_bounds__(kBlock) void stoprule_sum_kernel(const uint32_t* __restrict__ partials, int n, long long* __restrict__ pair,
+                                                              Published* host, long long seq) {
+    pulse_dev::sum_and_publish(partials, n, pair, reinterpret_cast<long long*>(host), seq);
+}
+__global__ void stoprule_publish_kernel(const long long* __restrict__ pair, Published* host, long long seq) {
+    host->local = pair[0]; host->global = pair[1];
+    __threadfence_system();
+    *reinterpret_cast<volatile long long*>(&host->seq) = seq;
+    __threadfence_system();
 }
 // set flags of a caller-owned bool tensor (the trainer's `terminated`), one partial per workgroup
 __global__ __launch_bounds__(kBlock) void stoprule_flags_kernel(const uint8_t* __restrict__ flags, int n, uint32_t* __restrict__ partials) {
@@ -127,47 +138,154 @@ __global__ __launch_bounds__(kBlock) void stoprule_flags_kernel(const uint8_t* _
     __syncthreads();
     if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kBlock / 64; ++k) t += w[k]; partials[blockIdx.x] = (uint32_t)t; }
 }
+
+// One cache line per (rank, slot) in a POSIX shared-memory segment: how the ranks of one node tell each other their
+// counts.  8 bytes per rank every 5 steps: a store and a few loads of host memory, no device involved.
+struct ShmRecord { long long count, seq, pad[6]; };
 }  // namespace
 
-struct PulseStopRule {
-    hipStream_t side;
-    hipEvent_t ready[kSlots], copied[kSlots];
-    uint32_t* partials_dev;               // [kSlots][max_partials]
-    long long* pair_dev;                  // [kSlots][2] = {local count, global count}
-    long long* pair_host;                 // pinned, same shape
-    int max_partials;
-    long long submitted, epoch_first;     // chunks submitted so far / first chunk of the current episode
-    int n_local; long long n_global; double threshold; int lag;
-    PulseComm* comm;
-};
+// The exchange as an object of its own (host code only: usable, and tested, without a GPU).  all_sum(index, value):
+// every rank calls it with the same sequence of indices; returns the sum of the ranks' values for that index.
+struct PulseShm { ShmRecord* mem; size_t bytes; int rank, world; };
 
-namespace pulse {
+extern "C" {
 
-// Slot the chunk about to be submitted will use; its previous occupant (kSlots chunks ago) must have landed.
-int stoprule_claim(PulseStopRule* h, int n_partials, uint32_t** partials_out) {
-    if (n_partials <= 0 || n_partials > h->max_partials) return fail(PULSE_EINVAL, "stop rule: too many partial counts for this handle");
-    const int slot = (int)(h->submitted % kSlots);
-    if (h->submitted >= kSlots) {
-        const hipError_t e = hipEventSynchronize(h->copied[slot]);
-        if (e != hipSuccess) return fail_hip((int)e, "stop rule: hipEventSynchronize");
-    }
-    *partials_out = h->partials_dev + (size_t)slot * h->max_partials;
+int pulse_shm_create(const char* name, int32_t rank, int32_t world, void** out) {
+    if (!name || !out || world < 1 || rank < 0 || rank >= world) return pulse::fail(PULSE_EINVAL, "pulse_shm_create: bad argument");
+    PulseShm* h = new PulseShm{nullptr, (size_t)world * kSlots * sizeof(ShmRecord), rank, world};
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)h->bytes) != 0) { if (fd >= 0) close(fd); delete h; return pulse::fail(PULSE_EINTERNAL, "pulse_shm_create: shm_open / ftruncate failed"); }
+    void* m = mmap(nullptr, h->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { delete h; return pulse::fail(PULSE_EINTERNAL, "pulse_shm_create: mmap failed"); }
+    h->mem = static_cast<ShmRecord*>(m);             // a fresh segment is zero-filled: seq 0 = nothing published
+    *out = h;
     return 0;
 }
 
-// The partial counts of the claimed slot are (being) written in `st` order: sum, all-reduce and copy them out on the side stream.
+int pulse_shm_all_sum(void* handle, int64_t index, int64_t value, int64_t* total) {
+    PulseShm* h = static_cast<PulseShm*>(handle);
+    if (!h || !total || index < 0) return pulse::fail(PULSE_EINVAL, "pulse_shm_all_sum: bad argument");
+    const int slot = (int)(index % kSlots);
+    ShmRecord* mine = h->mem + (size_t)h->rank * kSlots + slot;
+    // the slot's previous use (index - kSlots) has been read by every rank: each of them has since published index - kSlots + 1 .. index - 1
+    // only after reading it, and this rank has read those -- kSlots >= 2 suffices for that argument
+    mine->count = value;
+    __atomic_store_n(&mine->seq, (long long)index + 1, __ATOMIC_RELEASE);
+    long long sum = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < h->world; ++r) {
+        ShmRecord* rec = h->mem + (size_t)r * kSlots + slot;
+        for (long long spins = 1; __atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) != (long long)index + 1; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return pulse::fail(PULSE_EINTERNAL, "pulse_shm_all_sum: a rank did not publish its value within 120 s");
+        }
+        sum += rec->count;
+    }
+    *total = sum;
+    return 0;
+}
+
+int pulse_shm_destroy(void* handle) {
+    PulseShm* h = static_cast<PulseShm*>(handle);
+    if (!h) return 0;
+    munmap(h->mem, h->bytes);
+    delete h;
+    return 0;
+}
+
+}  // extern "C"
+
+enum { kModeLocal = 0, kModeRccl = 1, kModeShm = 2 };
+
+struct PulseStopRule {
+    int mode;
+    uint32_t* partials_dev;               // [kSlots][max_partials]
+    int n_partials[kSlots];
+    Published* host;                      // [kSlots], coherent pinned memory the publishing kernels write into
+    long long* pair_dev;                  // [kSlots][2] = {local count, global count} (RCCL path / flush scratch)
+    int max_partials;
+    long long submitted, epoch_first;     // check points submitted so far / first one of the current episode
+    long long scheduled;                  // check points whose publication has been enqueued (a launch carries it, or a flush did)
+    hipStream_t last_stream;              // where the newest check point's counts were written (a flush goes there)
+    int n_local; long long n_global; double threshold; int lag;
+    // RCCL exchange: side stream + events
+    PulseComm* comm; hipStream_t side; hipEvent_t ready[kSlots], copied[kSlots];
+    // shared-memory exchange
+    PulseShm* shm; int rank, world;
+};
+
+namespace {
+int wait_published(PulseStopRule* h, long long c) {
+    const int slot = (int)(c % kSlots);
+    volatile long long* seq = &h->host[slot].seq;
+    if (*seq == c + 1) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long long spins = 1; *seq != c + 1; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFF) == 0) {                       // now and then: is the device still alive?
+            const hipError_t q = hipStreamQuery(h->mode == kModeRccl ? h->side : h->last_stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return pulse::fail_hip((int)q, "stop rule: the stream that publishes the count");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                return pulse::fail(PULSE_EINTERNAL, "stop rule: no count after 60 s");
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 0;
+}
+
+// check point c has no later launch to carry its publication (lag 0, trainer flags): sum + publish it with a kernel of its own
+int flush(PulseStopRule* h, long long c) {
+    const int slot = (int)(c % kSlots);
+    hipLaunchKernelGGL(stoprule_sum_kernel, dim3(1), dim3(kBlock), 0, h->last_stream, h->partials_dev + (size_t)slot * h->max_partials,
+                       h->n_partials[slot], h->pair_dev + 2 * slot, h->host + slot, c + 1);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pulse::fail_hip((int)e, "stop rule: flush");
+    h->scheduled = c + 1;
+    return 0;
+}
+
+}  // namespace
+
+namespace pulse {
+
+// Slot the check point about to be submitted will use, and -- if the previous check point has not been scheduled for
+// publication yet -- what the launch about to be enqueued shall sum and publish on its way (an extra workgroup of it).
+int stoprule_claim(PulseStopRule* h, int n_partials, uint32_t** partials_out, StopRuleCarry* carry) {
+    if (n_partials <= 0 || n_partials > h->max_partials) return fail(PULSE_EINVAL, "stop rule: too many partial counts for this handle");
+    const int slot = (int)(h->submitted % kSlots);
+    // the slot's previous occupant (kSlots check points ago) must have been consumed: its verdict was due lag + 1 <= kSlots submissions ago
+    *partials_out = h->partials_dev + (size_t)slot * h->max_partials;
+    *carry = StopRuleCarry{nullptr, 0, nullptr, 0};
+    const long long prev = h->submitted - 1;
+    if (carry && h->mode != kModeRccl && prev >= 0 && h->scheduled < prev + 1) {
+        const int ps = (int)(prev % kSlots);
+        *carry = StopRuleCarry{h->partials_dev + (size_t)ps * h->max_partials, h->n_partials[ps], reinterpret_cast<long long*>(h->host + ps), prev + 1};
+        h->scheduled = prev + 1;
+    }
+    return 0;
+}
+
+// The partial counts of the claimed slot are (being) written in `st` order.
 int stoprule_commit(PulseStopRule* h, int n_partials, hipStream_t st) {
     const int slot = (int)(h->submitted % kSlots);
-    hipError_t e = hipEventRecord(h->ready[slot], st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ready[slot], 0);
-    if (e != hipSuccess) return fail_hip((int)e, "stop rule: event hand-off");
-    long long* pair = h->pair_dev + 2 * slot;
-    hipLaunchKernelGGL(stoprule_sum_kernel, dim3(1), dim3(kBlock), 0, h->side, h->partials_dev + (size_t)slot * h->max_partials, n_partials, pair);
-    if (h->comm && h->comm->world > 1)
+    h->n_partials[slot] = n_partials;
+    h->last_stream = st;
+    if (h->mode == kModeRccl) {            // sum -> all-reduce -> publish on the side stream (an event hands the chunk over)
+        hipError_t e = hipEventRecord(h->ready[slot], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ready[slot], 0);
+        if (e != hipSuccess) return fail_hip((int)e, "stop rule: event hand-off");
+        long long* pair = h->pair_dev + 2 * slot;
+        hipLaunchKernelGGL(stoprule_sum_kernel, dim3(1), dim3(kBlock), 0, h->side, h->partials_dev + (size_t)slot * h->max_partials, n_partials, pair,
+                           (Published*)nullptr, 0ll);
         if (int rc = pulse_comm_all_reduce_i64(h->comm, reinterpret_cast<const int64_t*>(pair), reinterpret_cast<int64_t*>(pair + 1), 1, h->side)) return rc;
-    e = hipMemcpyAsync(h->pair_host + 2 * slot, pair, 2 * sizeof(long long), hipMemcpyDeviceToHost, h->side);
-    if (e == hipSuccess) e = hipEventRecord(h->copied[slot], h->side);
-    if (e != hipSuccess) return fail_hip((int)e, "stop rule: copy to host");
+        hipLaunchKernelGGL(stoprule_publish_kernel, dim3(1), dim3(1), 0, h->side, pair, h->host + slot, h->submitted + 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(h->copied[slot], h->side);
+        if (e != hipSuccess) return fail_hip((int)e, "stop rule: publish to host");
+        h->scheduled = h->submitted + 1;
+    }
     ++h->submitted;
     return 0;
 }
@@ -176,24 +294,34 @@ int stoprule_commit(PulseStopRule* h, int n_partials, hipStream_t st) {
 
 extern "C" {
 
-int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, int32_t lag, void* comm, void** out) {
-    if (!out || n_local < 0 || n_global < n_local || lag < 0 || lag >= kSlots)
-        return pulse::fail(PULSE_EINVAL, "pulse_stoprule_create: need 0 <= n_local <= n_global and 0 <= lag < 4");
+int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, int32_t lag, void* comm, const char* shm_name,
+                          int32_t rank, int32_t world, void** out) {
+    if (!out || n_local < 0 || n_global < n_local || lag < 0 || lag >= kSlots - 1 || world < 1 || rank < 0 || rank >= world || (comm && shm_name))
+        return pulse::fail(PULSE_EINVAL, "pulse_stoprule_create: need 0 <= n_local <= n_global, 0 <= lag < 3, 0 <= rank < world, at most one of comm / shm_name");
     PulseStopRule* h = new PulseStopRule();
+    std::memset(h, 0, sizeof *h);
     h->n_local = n_local; h->n_global = n_global; h->threshold = threshold; h->lag = lag;
-    h->comm = static_cast<PulseComm*>(comm);
-    h->max_partials = (int)(((long long)n_local * 4 + 63) / 64) + 4;          // one per wavefront of a step launch (4 lanes per table)
+    h->comm = static_cast<PulseComm*>(comm); h->rank = rank; h->world = world;
+    h->mode = (h->comm && h->comm->world > 1) ? kModeRccl : (shm_name && world > 1) ? kModeShm : kModeLocal;
+    h->max_partials = (int)(((long long)n_local * 4 + 63) / 64) + 4;          // one per wavefront of a step launch (4 lanes per table at most)
     if (h->max_partials < kMaxPartials) h->max_partials = kMaxPartials;
-    hipError_t e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
-    for (int i = 0; i < kSlots && e == hipSuccess; ++i) {
-        e = hipEventCreateWithFlags(&h->ready[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->copied[i], hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->partials_dev), (size_t)kSlots * h->max_partials * sizeof(uint32_t));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->partials_dev), (size_t)kSlots * h->max_partials * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->pair_dev), kSlots * 2 * sizeof(long long));
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->pair_host), kSlots * 2 * sizeof(long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->host), kSlots * sizeof(Published), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess && h->mode == kModeRccl) {
+        e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+        for (int i = 0; i < kSlots && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&h->ready[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->copied[i], hipEventDisableTiming);
+        }
+    }
     if (e != hipSuccess) { delete h; return pulse::fail_hip((int)e, "pulse_stoprule_create"); }
-    std::memset(h->pair_host, 0, kSlots * 2 * sizeof(long long));
+    std::memset(h->host, 0, kSlots * sizeof(Published));
+    if (h->mode == kModeShm) {
+        void* shm = nullptr;
+        if (int rc = pulse_shm_create(shm_name, rank, world, &shm)) { (void)pulse_stoprule_destroy(h); return rc; }
+        h->shm = static_cast<PulseShm*>(shm);
+    }
     *out = h;
     return 0;
 }
@@ -201,10 +329,15 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
 int pulse_stoprule_destroy(void* handle) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!h) return 0;
-    (void)hipStreamSynchronize(h->side);
-    for (int i = 0; i < kSlots; ++i) { (void)hipEventDestroy(h->ready[i]); (void)hipEventDestroy(h->copied[i]); }
-    (void)hipFree(h->partials_dev); (void)hipFree(h->pair_dev); (void)hipHostFree(h->pair_host);
-    (void)hipStreamDestroy(h->side);
+    if (h->mode == kModeRccl) {
+        (void)hipStreamSynchronize(h->side);
+        for (int i = 0; i < kSlots; ++i) { (void)hipEventDestroy(h->ready[i]); (void)hipEventDestroy(h->copied[i]); }
+        (void)hipStreamDestroy(h->side);
+    } else if (h->last_stream || h->submitted) {
+        (void)hipStreamSynchronize(h->last_stream);       // a launch may still be about to write into the pinned block
+    }
+    if (h->shm) (void)pulse_shm_destroy(h->shm);
+    (void)hipFree(h->partials_dev); (void)hipFree(h->pair_dev); (void)hipHostFree(h->host);
     delete h;
     return 0;
 }
@@ -214,21 +347,28 @@ int pulse_stoprule_submit(void* handle, const uint8_t* flags, int32_t n, void* s
     if (!h || !flags || n < 0) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_submit: bad argument");
     const int grid = n == 0 ? 1 : min(kMaxPartials, (n + kBlock - 1) / kBlock);
     uint32_t* partials = nullptr;
-    if (int rc = pulse::stoprule_claim(h, grid, &partials)) return rc;
+    pulse::StopRuleCarry none;
+    if (h->mode != kModeRccl && h->submitted > 0 && h->scheduled < h->submitted)         // an unpublished roll-out check point: flush it first
+        if (int rc = flush(h, h->submitted - 1)) return rc;
+    if (int rc = pulse::stoprule_claim(h, grid, &partials, &none)) return rc;
     hipLaunchKernelGGL(stoprule_flags_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, flags, n, partials);
-    return pulse::stoprule_commit(h, grid, (hipStream_t)stream);
+    if (int rc = pulse::stoprule_commit(h, grid, (hipStream_t)stream)) return rc;
+    if (h->mode != kModeRccl) return flush(h, h->submitted - 1);      // no later launch of ours will carry it
+    return 0;
 }
 
 int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t* have) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!h || !local || !global || !have) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_counts: null argument");
-    const long long c = h->submitted - 1 - h->lag;          // the chunk whose verdict is due now
+    const long long c = h->submitted - 1 - h->lag;          // the check point whose verdict is due now
     *have = 0; *local = 0; *global = 0;
     if (c < h->epoch_first) return 0;
+    if (h->scheduled < c + 1) if (int rc = flush(h, c)) return rc;       // lag 0: nothing else will publish it
+    if (int rc = wait_published(h, c)) return rc;
     const int slot = (int)(c % kSlots);
-    const hipError_t e = hipEventSynchronize(h->copied[slot]);       // normally long complete: `lag` chunks are queued behind it
-    if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_stoprule_counts: hipEventSynchronize");
-    *local = h->pair_host[2 * slot]; *global = h->pair_host[2 * slot + 1]; *have = 1;
+    long long loc = h->host[slot].local, glob = h->host[slot].global;
+    if (h->mode == kModeShm) { int64_t total = 0; if (int rc = pulse_shm_all_sum(h->shm, c, loc, &total)) return rc; glob = total; }
+    *local = loc; *global = glob; *have = 1;
     return 0;
 }
 
@@ -244,7 +384,7 @@ int pulse_stoprule_decide(void* handle, int32_t* over) {
 int pulse_stoprule_drain(void* handle) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_drain: null argument");
-    h->epoch_first = h->submitted;           // chunks of the finished episode never decide anything again
+    h->epoch_first = h->submitted;           // check points of the finished episode never decide anything again
     return 0;
 }
 

@@ -50,7 +50,7 @@ _ROWS = ("stacks", "current_round_bet", "total_invested", "status")
 _TRACKED = frozenset(_I32_SCALARS + _BOOL_SCALARS + _ROWS + ("hands", "board", "decks", "equities", "obs",
                                                              "w1", "w2", "K", "alpha", "hand_ranks",
                                                              "active_players", "n_players", "n_games", "max_players",
-                                                             "use_eval_cache", "obs_staging", "chunked_rollout"))
+                                                             "use_eval_cache", "obs_staging", "chunked_rollout", "lanes_per_table"))
 
 
 class PokerGPU(_EnvBase):
@@ -99,6 +99,7 @@ class PokerGPU(_EnvBase):
         self.use_eval_cache = True       # reset fills the evaluation cache, steps read it
         self.obs_staging = True          # observations leave as LDS-staged 16-byte bursts (needs n_games % 16 == 0)
         self.chunked_rollout = True      # rollout(): one launch per chunk of steps instead of one per step
+        self.lanes_per_table = None      # None: 4 lanes per table for a single step, 2 for a chunk; or force 2 / 4
         # opt-in: successive steps write their observation into two alternating buffers, so the tensor a step returned
         # stays intact through the NEXT step (a trainer then needs no copy of the pre-step observation).  Off: the
         # reference's single persistent buffer (PokerGPU.py:633).
@@ -229,7 +230,10 @@ class PokerGPU(_EnvBase):
             v = _native.PokerView()
             v.n_games, v.n_players, v.active_players, v.max_players = N, P, A, self.max_players
             v.obs_size, v.hand_ranks_len = self.obs_size, hr.numel()
-            v.flags = (0 if self.obs_staging else _native.VIEW_NO_OBS_STAGING) | (0 if self.chunked_rollout else _native.VIEW_NO_CHUNK)
+            if self.lanes_per_table not in (None, 2, 4):
+                raise ValueError(f"lanes_per_table must be None, 2 or 4, got {self.lanes_per_table!r}")
+            v.flags = ((0 if self.obs_staging else _native.VIEW_NO_OBS_STAGING) | (0 if self.chunked_rollout else _native.VIEW_NO_CHUNK)
+                       | {None: 0, 2: _native.VIEW_LANES2, 4: _native.VIEW_LANES4}[self.lanes_per_table])
             v.hand_ranks = hr.data_ptr()
             for k, p in ptr.items():
                 setattr(v, k, p)
@@ -284,8 +288,15 @@ class PokerGPU(_EnvBase):
                 raise ValueError(f"active_players must be in [2, {self.n_players}], got {ap}")
             candidate_players = ap
         q_seat = options.get('q_agent_seat', 0)
-        self.active_players = int(max(candidate_players, q_seat + 1))
-        A, N = self.active_players, self.n_games
+        A, N = int(max(candidate_players, q_seat + 1)), self.n_games
+        if self._view_dirty or not (2 <= A <= self.n_players):
+            self.active_players = A
+        else:
+            # only the number of seats in the hand changes between episodes: patch the cached C views in place instead
+            # of rebuilding (and re-validating) them -- that rebuild was most of the idle time at an episode boundary
+            object.__setattr__(self, "active_players", A)
+            for v in (*self._views, self._view_inplace):
+                v.active_players = A
 
         prefixed_decks = options.get("prefixed_decks")
         deck_tensor = None
@@ -296,7 +307,10 @@ class PokerGPU(_EnvBase):
                 raise ValueError(f"prefixed_decks must have shape {expected_shape}, got {tuple(deck_tensor.shape)}")
             deck_tensor = deck_tensor.contiguous()
 
-        self.equities = self._equities_store[:N * A].view(N, A)
+        if self._view_dirty:
+            self.equities = self._equities_store[:N * A].view(N, A)
+        else:       # same storage, same pointer: only the shape the attribute shows changes
+            object.__setattr__(self, "equities", self._equities_store[:N * A].view(N, A))
         v = self._view(inplace=True)
         o = _native.PokerResetOpts()
         o.first = 0 if self._has_episode else 1
@@ -383,6 +397,38 @@ class PokerGPU(_EnvBase):
         object.__setattr__(self, "is_done", self._done_bufs[new_pp])
         object.__setattr__(self, "obs", self._obs_bufs[new_pp])
         return self.obs, self._rewards[last], self.is_done, self.is_truncated, self.get_info()
+
+    def rollout_until(self, agent_types, actions, chunk_steps, max_steps, step_counter0, stop_rule, timer=None, time_every=0):
+        """The trainer's inner loop for scripted tables without the interpreter in it (pulse_poker_rollout_until): chunks
+        of `chunk_steps` fused policy+step transitions, the stop rule's verdict after each, until it ends the episode
+        or `max_steps` steps have run.  Returns (steps_done, over).  `stop_rule` must decide natively
+        (stoprule.LaggedDoneCount with exchange "local" or "rccl"); with a host-side exchange call rollout() + over()
+        per chunk instead."""
+        if stop_rule is None or getattr(stop_rule, "handle", None) is None or stop_rule.exchange == "host":
+            raise ValueError("rollout_until needs a stop rule that decides natively (exchange 'local' or 'rccl')")
+        actions = self._actions(actions)
+        key = tuple(int(x) for x in agent_types)
+        types = self._types_cache.get(key)
+        if types is None:
+            if len(key) != self.n_players:
+                raise ValueError(f"agent_types must have {self.n_players} entries, got {len(key)}")
+            types = self._types_cache[key] = (C.c_uint8 * self.n_players)(*key)
+        if self._view_dirty:
+            self._build_views()
+        pp = self._pp
+        done, over = C.c_int32(0), C.c_int32(0)
+        _native.check(self._lib.pulse_poker_rollout_until(
+            C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types, self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
+            actions.data_ptr(), self._rewards[pp].data_ptr(), self._rewards[1 - pp].data_ptr(), int(chunk_steps), int(max_steps),
+            None if timer is None else timer.handle, int(time_every), stop_rule.handle, self._stream(), C.byref(done), C.byref(over)),
+            "pulse_poker_rollout_until")
+        stop_rule.decisions += -(-done.value // max(int(chunk_steps), 1))
+        if done.value % 2:
+            new_pp = 1 - pp
+            object.__setattr__(self, "_pp", new_pp)
+            object.__setattr__(self, "is_done", self._done_bufs[new_pp])
+            object.__setattr__(self, "obs", self._obs_bufs[new_pp])
+        return done.value, bool(over.value)
 
     # ------------------------------------------------------------------ white-box methods
     def _phases(self, phases, actions=None, actor_idx=None, rewards=None):

@@ -9,8 +9,11 @@ decides on the same chunk from the same global count, so all ranks end every epi
 identical sequences of collectives.  `lag=0` is the reference's blocking check.
 
 Who exchanges the counts between ranks:
-  * `exchange="rccl"` (default with the nccl backend): the native library's own RCCL communicator, enqueued on the
-    rule's side stream by the same native call that enqueues the steps -- no Python, no host wait (csrc/stoprule.hip);
+  * `exchange="shm"` (default with the nccl backend, i.e. one process per GPU on one node): every rank writes its
+    count into its cache line of a POSIX shared-memory segment and reads the others' -- host memory only, inside the
+    native decide() call, no collective to launch (csrc/stoprule.hip);
+  * `exchange="rccl"`: the native library's own RCCL communicator, an 8-byte all-reduce on the rule's side stream (an
+    event per check point hands the counts over, which costs the steps' stream a barrier each time);
   * `exchange="host"` (gloo, i.e. the CPU tests and the one-GPU rehearsal): the local count of the due chunk is read
     from pinned memory and all-reduced with torch.distributed by `over()`;
   * `exchange="local"` (one process): nothing to exchange.
@@ -19,6 +22,7 @@ time than the chunk's five steps take on the GPU."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -60,6 +64,27 @@ class NativeComm:
             self.handle = None
 
 
+class ShmExchange:
+    """The native shared-memory exchange (pulse_shm_*): all_sum(index, value) over the ranks of one node.  Host code
+    only; the native stop rule owns one itself, this wrapper serves the HostCounts backend (CPU tests)."""
+
+    def __init__(self, name: str, rank: int, world: int):
+        self._lib = _native.lib()
+        h = C.c_void_p()
+        _native.check(self._lib.pulse_shm_create(name.encode(), rank, world, C.byref(h)), "pulse_shm_create")
+        self.handle = h
+
+    def all_sum(self, index: int, value: int) -> int:
+        total = C.c_int64(0)
+        _native.check(self._lib.pulse_shm_all_sum(self.handle, int(index), int(value), C.byref(total)), "pulse_shm_all_sum")
+        return total.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.pulse_shm_destroy(self.handle)
+            self.handle = None
+
+
 def _dist_world(group=None) -> int:
     import torch.distributed as dist
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -71,8 +96,8 @@ class HostCounts:
     world-size-2 gloo tests drive on CPU; the product path uses the native handle."""
 
     def __init__(self, lag: int = 1):
-        if not 0 <= lag < 4:
-            raise ValueError("need 0 <= lag < 4")
+        if not 0 <= lag < 3:
+            raise ValueError("need 0 <= lag < 3")
         self.lag, self.submitted, self.epoch_first, self._counts = int(lag), 0, 0, {}
 
     def submit_count(self, n_done: int) -> None:
@@ -105,11 +130,11 @@ class LaggedDoneCount:
                 exchange = "local"
             else:
                 import torch.distributed as dist
-                exchange = "rccl" if dist.get_backend(group) == "nccl" else "host"
-        if exchange not in ("local", "host", "rccl"):
-            raise ValueError(f"exchange must be 'local', 'host' or 'rccl', got {exchange!r}")
+                exchange = "shm" if dist.get_backend(group) == "nccl" else "host"
+        if exchange not in ("local", "host", "rccl", "shm"):
+            raise ValueError(f"exchange must be 'local', 'host', 'shm' or 'rccl', got {exchange!r}")
         if backend is not None and exchange == "rccl":
-            raise ValueError("a host-side count backend cannot use the native RCCL exchange")
+            raise ValueError("a host-side count backend cannot use the RCCL exchange")
         if exchange != "local" and world == 1:
             exchange = "local"
         self.exchange = exchange
@@ -124,20 +149,59 @@ class LaggedDoneCount:
         self._own_comm = None
         self.comm = None
         self.handle = None
+        self._shm = None
         if backend is not None:
             if backend.lag != self.lag:
                 raise ValueError("backend.lag differs from lag")
+            if exchange == "shm":
+                import torch.distributed as dist
+                name = self._shared_name(device, group)
+                self._shm = ShmExchange(name, dist.get_rank(group), world)
+                dist.barrier(group)
+                if dist.get_rank(group) == 0:
+                    try:
+                        os.unlink("/dev/shm" + name)
+                    except OSError:
+                        pass
             return
         self._lib = _native.lib()
         if exchange == "rccl" and comm is None:
             comm = self._own_comm = NativeComm(device, group)
         self.comm = comm if exchange == "rccl" else None
+        rank, shm_name = 0, None
+        if exchange == "shm":
+            import torch.distributed as dist
+            rank = dist.get_rank(group)
+            shm_name = self._shared_name(device, group)
         h = C.c_void_p()
         with torch.cuda.device(device):
             _native.check(self._lib.pulse_stoprule_create(self.n, self.n_global, self.threshold, self.lag,
-                                                          self.comm.handle if self.comm is not None else None, C.byref(h)),
-                          "pulse_stoprule_create")
+                                                          self.comm.handle if self.comm is not None else None,
+                                                          shm_name.encode() if shm_name else None, rank, world if exchange == "shm" else 1,
+                                                          C.byref(h)), "pulse_stoprule_create")
         self.handle = h
+        if exchange == "shm":              # every rank has the segment mapped: its name can go
+            import torch.distributed as dist
+            dist.barrier(group)
+            if rank == 0:
+                try:
+                    os.unlink("/dev/shm" + shm_name)
+                except OSError:
+                    pass
+
+    _shm_counter = 0
+
+    @classmethod
+    def _shared_name(cls, device, group):
+        """A segment name all ranks agree on: rank 0 picks it (its pid + a counter), the group broadcasts 8 bytes."""
+        import torch.distributed as dist
+        cls._shm_counter += 1
+        ident = torch.tensor([os.getpid(), cls._shm_counter], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            ident = ident.to(torch.device(device))
+        dist.broadcast(ident, src=0, group=group)
+        pid, k = (int(x) for x in ident.cpu().tolist())
+        return f"/pulse_stoprule_{pid}_{k}"
 
     def submit(self, flags: torch.Tensor) -> None:
         """One check point: count the set flags of `flags` (bool/uint8[n]) in stream order.
@@ -169,8 +233,11 @@ class LaggedDoneCount:
             self.exchanges += 1
             return float(t.item()) > self.threshold * self.n_global
         if self.backend is not None:
-            _, glob, have = self.backend.counts()
+            loc, glob, have = self.backend.counts()
             self.decisions += 1
+            if have and self._shm is not None:
+                glob = self._shm.all_sum(self.backend.submitted - 1 - self.lag, loc)
+                self.exchanges += 1
             return have and glob > self.threshold * self.n_global
         flag = C.c_int32(0)
         _native.check(self._lib.pulse_stoprule_decide(self.handle, C.byref(flag)), "pulse_stoprule_decide")
@@ -191,9 +258,12 @@ class LaggedDoneCount:
         if self._own_comm is not None:
             self._own_comm.close()
             self._own_comm = None
+        if getattr(self, "_shm", None) is not None:
+            self._shm.close()
+            self._shm = None
 
-    # no __del__: at interpreter shutdown the HIP runtime may already be gone, and an unclosed handle only leaks a side
-    # stream, eight events and < 1 MB; long-lived callers call close()
+    # no __del__: at interpreter shutdown the HIP runtime may already be gone, and an unclosed handle only leaks
+    # < 1 MB; long-lived callers call close()
 
 
 class RolloutTimer:

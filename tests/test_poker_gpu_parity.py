@@ -127,7 +127,7 @@ def _seeded_decks(n, seed):
     return (torch.rand((n, 52), generator=g).argsort(dim=1) + 1).to(torch.int32)
 
 
-@pytest.mark.parametrize("variant", ["default", "no_eval_cache", "no_obs_staging"])
+@pytest.mark.parametrize("variant", ["default", "no_eval_cache", "no_obs_staging", "two_lanes_per_table"])
 @pytest.mark.parametrize("N,P,As", [(65536, 10, (10, 7, 2)), (4099, 6, (6, 3)), (4096, 6, (6, 3)), (1, 2, (2,)), (17, 16, (16, 9))])
 def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
     """Config-2 size (65,536 tables, 10 seats) and ragged sizes: every step compared with the oracle -- with the
@@ -141,6 +141,7 @@ def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
     env = _gpu_env(**kw)
     env.use_eval_cache = variant != "no_eval_cache"
     env.obs_staging = variant != "no_obs_staging"
+    env.lanes_per_table = 2 if variant == "two_lanes_per_table" else None        # the single step defaults to four
     ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
     rng = np.random.default_rng(N + P)
     tol = reward_tol(50)
@@ -625,7 +626,7 @@ def test_native_stop_rule_fixed_lag_counts_and_drains():
     rule.submit(flags)
     assert rule.over() is True
     rule.close()
-    for lag in (1, 2, 3):
+    for lag in (1, 2):
         r = LaggedDoneCount(dev, n, 0.8, lag=lag)
         fracs = [0.0, 0.5, 0.9, 0.1, 0.85, 0.85, 0.2, 0.95]
         verdicts = []
@@ -648,7 +649,7 @@ def test_native_stop_rule_fixed_lag_counts_and_drains():
         assert after == [False] * (lag + 2), (lag, after)
         r.close()
     with pytest.raises(ValueError):
-        LaggedDoneCount(dev, n, 0.8, lag=4)
+        LaggedDoneCount(dev, n, 0.8, lag=3)
     # inside the native rollout call: the done flags of the state the last step produced, chunked or not
     for chunked in (True, False):
         env = _gpu_env(n_players=6, max_players=10, n_games=4096, seed=3)
@@ -671,13 +672,54 @@ def test_native_stop_rule_fixed_lag_counts_and_drains():
         r2.close()
 
 
+@pytest.mark.parametrize("lag", [1, 0, 2])
+def test_native_episode_loop_equals_rollout_plus_verdict_per_chunk(lag):
+    """pulse_poker_rollout_until (chunks + stop-rule verdicts in one native call) against the same episode driven from
+    Python, chunk by chunk: same number of steps, same verdict, identical memory -- also when `max_steps` cuts the
+    episode (odd and even step counts: the two ping-pong views swap roles)."""
+    from pulselib_amd.stoprule import LaggedDoneCount
+    dev = torch.device(DEV)
+    N = 4096
+    kw = dict(n_players=6, max_players=10, n_games=N, seed=21, table_id0=3)
+    a, b = _gpu_env(**kw), _gpu_env(**kw)
+    ra, rb = LaggedDoneCount(dev, N, 0.8, lag=lag), LaggedDoneCount(dev, N, 0.8, lag=lag)
+    types = [1, 3, 2, 4, 5, 1]
+    acts = [torch.zeros(N, dtype=torch.long, device=dev) for _ in range(2)]
+    gstep, fired = 0, False
+    for e, cap in enumerate((60, 13, 22, 60)):
+        for env, rule in ((a, ra), (b, rb)):
+            env.reset(options={"active_players": 6 - e % 2, "rotation": e})
+            rule.drain()
+        n_native, over_native = a.rollout_until(types, acts[0], 5, cap, gstep, ra)
+        n_py, over_py = 0, False
+        while n_py < cap and not over_py:
+            n = min(5, cap - n_py)
+            b.rollout(types, acts[1], n, gstep + n_py, stop_rule=rb)
+            n_py += n
+            over_py = rb.over()
+        assert (n_native, over_native) == (n_py, over_py), f"episode {e}"
+        assert n_native <= cap and (over_native or n_native == cap), f"episode {e}"
+        fired = fired or over_native
+        gstep += n_native
+        for name in ROLLOUT_MEMORY:
+            np.testing.assert_array_equal(to_np(getattr(a, name)), to_np(getattr(b, name)), err_msg=f"episode {e} {name}")
+        for k in range(2):
+            np.testing.assert_array_equal(to_np(a._obs_bufs[k]), to_np(b._obs_bufs[k]), err_msg=f"episode {e} obs buffer {k}")
+            np.testing.assert_array_equal(to_np(a._rewards[k]), to_np(b._rewards[k]), err_msg=f"episode {e} rewards buffer {k}")
+        assert a._pp == b._pp and a.obs.data_ptr() == a._obs_bufs[a._pp].data_ptr()
+        np.testing.assert_array_equal(to_np(acts[0]), to_np(acts[1]))
+    assert fired, "the rule never fired: the test would not cover the verdict path"
+    ra.close(); rb.close()
+
+
 ROLLOUT_MEMORY = INT_KEYS + ("decks", "equities", "prev_stacks", "prev_invested", "equity_dirty")
 
 
 @pytest.mark.parametrize("N,P,MP", [(4096, 10, 10), (4099, 10, 10), (17, 6, 10), (1, 2, 2), (2048, 16, 16), (1040, 13, 16)],
                          ids=["4096x10", "ragged4099", "17x6", "1x2", "2048x16", "1040x13of16"])
 @pytest.mark.parametrize("dbl", [False, True], ids=["one-obs-buffer", "two-obs-buffers"])
-def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl):
+@pytest.mark.parametrize("lanes", [None, 4, 2], ids=["default-lanes", "4-lanes", "2-lanes"])
+def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl, lanes):
     """pulse_poker_rollout as ONE launch per chunk (state in registers across the steps) against the same call issuing
     one launch per step (PULSE_VIEW_NO_CHUNK): every state tensor, BOTH observation buffers, BOTH reward buffers, both
     done buffers and the actions are bit-identical after every chunk -- chunk lengths 1..19 from odd and even step
@@ -685,6 +727,7 @@ def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl):
     kw = dict(n_players=P, max_players=MP, n_games=N, w1=.5, w2=.3, K=100, alpha=50, seed=91, table_id0=7)
     one, per = _gpu_env(**kw), _gpu_env(**kw)
     per.chunked_rollout = False
+    one.lanes_per_table = lanes          # the per-step side keeps its default (four lanes): the two mappings must agree too
     one.double_buffer_obs = per.double_buffer_obs = dbl
     types = ([0, 3, 2, 2, 4, 3, 1, 4, 5, 3, 1, 2, 3, 4, 5, 1])[:P]          # seat 0 external
     rng = np.random.default_rng(5)

@@ -24,7 +24,7 @@ def _free_port():
 def test_host_counts_fixed_lag_matches_the_native_rule_contract():
     """Verdict of check point c comes right after check point c + lag was submitted; an episode boundary silences
     everything submitted before it (the same cases tests/test_poker_gpu_parity.py runs against the native handle)."""
-    for lag in (0, 1, 2, 3):
+    for lag in (0, 1, 2):
         r = LaggedDoneCount(torch.device("cpu"), 10000, 0.8, lag=lag, backend=HostCounts(lag))
         assert r.exchange == "local" and r.over() is False
         fracs = [0.0, 0.5, 0.9, 0.1, 0.85, 0.8, 0.2, 0.95]
@@ -59,7 +59,7 @@ class _FakeEnv:
         stop_rule.backend.submit_count(int(min(1.0, self.rate * self.steps) * N_LOCAL))
 
 
-def _bench_worker(rank, world, port, lag, out):
+def _bench_worker(rank, world, port, lag, exchange, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -67,8 +67,9 @@ def _bench_worker(rank, world, port, lag, out):
         log, collectives = [], []
         # rank 0's tables finish three times as fast as rank 1's: a rank-local rule would end episodes at different steps
         env = _FakeEnv(rate=(0.09, 0.03)[rank], log=log)
-        rule = LaggedDoneCount(torch.device("cpu"), N_LOCAL, 0.8, lag=lag, n_global=N_LOCAL * world, backend=HostCounts(lag))
-        assert rule.exchange == "host"
+        rule = LaggedDoneCount(torch.device("cpu"), N_LOCAL, 0.8, lag=lag, n_global=N_LOCAL * world, backend=HostCounts(lag),
+                               exchange=exchange)
+        assert rule.exchange == (exchange or "host")
 
         def on_end(loop):                     # the per-episode statistics all-reduce of bench.py's EpisodeStatsReducer
             t = torch.tensor([float(env.steps), 1.0], dtype=torch.float64)
@@ -86,10 +87,12 @@ def _bench_worker(rank, world, port, lag, out):
 
 
 def test_two_ranks_with_different_done_rates_end_every_episode_together():
-    for lag in (1, 0, 2):
+    """exchange None = torch.distributed all-reduce of the count (gloo); "shm" = the native shared-memory exchange
+    (pulse_shm_*), the default of the nccl backend -- real cross-process traffic in both cases."""
+    for lag, exchange in ((1, None), (0, None), (2, None), (1, "shm"), (0, "shm")):
         mgr = mp.Manager()
         out = mgr.dict()
-        mp.spawn(_bench_worker, args=(2, _free_port(), lag, out), nprocs=2, join=True)
+        mp.spawn(_bench_worker, args=(2, _free_port(), lag, exchange, out), nprocs=2, join=True)
         a, b = out[0], out[1]
         assert a["log"] == b["log"], "ranks issued different reset / roll-out sequences"
         assert a["collectives"] == b["collectives"] and len(a["collectives"]) == a["episodes"] - 1
@@ -128,6 +131,30 @@ def _trainer_rule_worker(rank, world, port, out):
         out[rank] = ends
     finally:
         dist.destroy_process_group()
+
+
+def _shm_worker(rank, world, name, out):
+    from pulselib_amd.stoprule import ShmExchange
+    x = ShmExchange(name, rank, world)
+    got = [x.all_sum(i, (rank + 1) * 1000 + i) for i in range(2000)]        # far more rounds than slots: they are reused safely
+    x.close()
+    out[rank] = got
+
+
+def test_shared_memory_exchange_sums_over_three_processes():
+    """pulse_shm_all_sum: every rank contributes one value per index and reads the sum; 2,000 rounds through 4 slots."""
+    world, name = 3, f"/pulse_test_shm_{os.getpid()}"
+    mgr = mp.Manager()
+    out = mgr.dict()
+    try:
+        mp.spawn(_shm_worker, args=(world, name, out), nprocs=world, join=True)
+    finally:
+        try:
+            os.unlink("/dev/shm" + name)
+        except OSError:
+            pass
+    want = [sum((r + 1) * 1000 + i for r in range(world)) for i in range(2000)]
+    assert out[0] == out[1] == out[2] == want
 
 
 def test_trainer_cadence_breaks_at_the_same_step_on_both_ranks():

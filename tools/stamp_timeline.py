@@ -25,9 +25,10 @@ lib.pulse_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.pulse_debug_set_stamp_buffer.restype = C.c_int
 env = PokerGPU(device=dev, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
                K=100, alpha=50, seed=1)
+env.lanes_per_table = int(sys.argv[3]) if len(sys.argv) > 3 else None
 native, q_seat, rot = bench.native_types_for_episode(0)
 actions = torch.zeros(N, dtype=torch.long, device=dev)
-n_waves = (N * 4 + 63) // 64
+n_waves = (N * 4 + 63) // 64          # sized for four lanes per table (fewer wavefronts with two)
 buf = torch.zeros((n_waves, 16), dtype=torch.int64, device=dev)
 names = ["launch->start", "issue loads", "wait loads+pick actor", "policy", "equities", "execute+masks", "advance/deal", "payouts",
          "reward", "obs stores", "state stores", "drain stores"]
@@ -44,6 +45,7 @@ for A, warm in ((8, 6), (8, 20), (6, 33)):
         env.rollout(native, actions, STEPS, 1000 + 10 * r)
         torch.cuda.synchronize()
         st = buf.cpu().numpy().astype(np.int64)
+        st = st[st[:, 0] != 0]
         d = np.diff(st[:, :12], axis=1)
         acc += d.mean(axis=0)
         total.append((st[:, 11].max() - st[:, 0].min(), (st[:, 11] - st[:, 0]).mean(), st[:, 0].max() - st[:, 0].min()))
