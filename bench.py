@@ -70,7 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--min-episodes", type=int, default=8, help="... and span at least this many episodes")
     ap.add_argument("--max-repeats", type=int, default=4000)
     ap.add_argument("--per-step-launches", action="store_true", help="one launch per step instead of one per chunk (A/B)")
-    ap.add_argument("--lanes", type=int, choices=[0, 2, 4], default=0, help="lanes per table (A/B); 0 = the library's default")
+    ap.add_argument("--stop-exchange", choices=["auto", "host", "shm", "rccl"], default="auto",
+                    help="how the ranks exchange the stop rule's counts (auto: shared memory with the nccl backend, torch.distributed with gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--trainer-loop", choices=["auto", "on", "off"], default="auto", help="auto: at N = 1")
@@ -339,8 +340,8 @@ def main_rank(args):
     env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100,
                    max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=SEED, table_id0=rank * N)
     env.chunked_rollout = not args.per_step_launches
-    env.lanes_per_table = args.lanes or None
-    rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world)
+    rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world,
+                           exchange=None if args.stop_exchange == "auto" else args.stop_exchange)
     stats = EpisodeStatsReducer(env, device, world)
     actions = torch.zeros(N, dtype=torch.long, device=device)
     loop = EpisodeLoop(env, rule, actions, args.max_episode_steps, on_episode_end=stats)

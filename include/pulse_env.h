@@ -62,8 +62,6 @@ enum {
 /* flags: kernel variants a caller (or a test) selects per view; 0 = the product defaults */
 #define PULSE_VIEW_NO_OBS_STAGING 0x1  /* store the observation column by column instead of LDS-staged 16-byte bursts  */
 #define PULSE_VIEW_NO_CHUNK       0x2  /* pulse_poker_rollout: one launch per step instead of one launch per chunk     */
-#define PULSE_VIEW_LANES2         0x4  /* two lanes per table in every launch  (default: 2 for a chunk, 4 for a step)  */
-#define PULSE_VIEW_LANES4         0x8  /* four lanes per table in every launch                                         */
 typedef struct PulsePokerView {
     int32_t n_games, n_players, active_players, max_players;   /* n_games <= 2^24 per view (shard larger batches) */
     int32_t obs_size, hand_ranks_len;
@@ -181,7 +179,7 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
  * (pulse_stoprule_decide), until the rule ends the episode or max_steps steps have run -- no interpreter between the
  * chunks.  *steps_done: steps executed (the caller's views / reward buffers have swapped roles if it is odd);
  * *over: the rule fired.  timer + time_every > 0: every time_every-th chunk opens a HIP-event bracket over the next
- * four chunks of the call (an event pair around every single launch costs the stream a fifth of the launch). */
+ * eight chunks of the call (an event pair around every single launch costs the stream a fifth of the launch). */
 int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                               uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
                               float* rewards_even, float* rewards_odd, int32_t chunk_steps, int32_t max_steps, void* timer,

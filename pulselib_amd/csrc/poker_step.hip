@@ -8,9 +8,7 @@
 // scalar part of the state machine costs 1/LPT wave-instruction per table; per-seat rows ([N,P] int32, the reference's
 // own layout) are SPL unrolled dwords per lane.  Seat sets (ACTIVE seats, contenders, winners) are bitmasks OR-reduced
 // across the table's lanes with DPP quad_perm modifiers (no LDS); "first ACTIVE seat after x" is a rotate + ffs on the
-// mask; side-pot layers are min/max butterflies.  Four lanes per table give the single-step launch (bound by memory
-// latency) the most wavefronts in flight; two lanes halve the replicated scalar work of the chunk kernel, which is
-// bound by vector-instruction issue.  All integer arithmetic is the reference's; the fp32 reward keeps
+// mask; side-pot layers are min/max butterflies.  LPT = 4 is what is built (see lanes_for below for the measurement).  All integer arithmetic is the reference's; the fp32 reward keeps
 // torch's op order (no contraction; tanh rounded once from double).
 //
 // Memory: single step -- state is read once and only the words that changed are written back, in the reference's
@@ -25,9 +23,9 @@ using namespace pulse_dev;
 namespace {
 
 // dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
-// (hole cards [16][P_][2], cache tags [16][P_], ranks [16][P_], street equities [16][3][P_], deck window [16][8]);
+// (hole cards [16][P_][2], ranks [16][P_], street equities [16][3][P_], deck window [16][8]);
 // 16-byte aligned so that the observation block of the next wavefront is.
-__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 7 + 8) + 3) & ~3; }
+__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 6 + 8) + 3) & ~3; }
 
 struct PolicyArgs {
     uint64_t types_packed, seed, step_counter, table_id0;
@@ -54,10 +52,40 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i) do { } while (0)
 #endif
 
-// tanh rounded once from double: 1 - 2/(exp(2x)+1) (abs. error ~1e-16, far below the fp32 ulp)
+// tanh rounded once from double: 1 - 2/(exp(2x)+1), everything in double (abs. error ~1e-16, far below the fp32 ulp:
+// the result is the correctly rounded fp32 tanh except in ~1e-8 of cases).  The exponential is written out -- the
+// library's exp + IEEE division carry special-case handling this argument range never needs, and double-precision
+// vector instructions issue at half rate, so they were a sixth of the kernel's vector work: k = rint(y log2 e),
+// r = y - k ln 2 (two-part constant), e^r by its Taylor series to r^13 (|r| <= 0.347: remainder < 5e-18), 2^k by
+// ldexp; the reciprocal is v_rcp_f64 + two Newton steps.  Below |x| = 1e-3 the difference 1 - 2/(..) cancels, and
+// x (1 - x^2/3) is exact to double rounding instead.  Against libm's tanh rounded to fp32: 2 of 4e7 arguments differ.
 __device__ __forceinline__ float tanh_rn(float x) {
-    const double e2 = exp(2.0 * (double)x);
-    return (float)(1.0 - 2.0 / (e2 + 1.0));
+    const double xd = (double)x;
+    double y = 2.0 * xd;
+    y = fmin(fmax(y, -40.0), 40.0);                       // tanh is +-1 in fp32 long before; keeps 2^k finite
+    const double k = rint(y * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, y);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                    // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                  // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                 // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                 // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                  // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                 // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);                 // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                 // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double d = ldexp(p, (int)k) + 1.0;              // exp(2x) + 1
+    double q = __builtin_amdgcn_rcp(d);
+    q = fma(fma(-d, q, 1.0), q, q);
+    q = fma(fma(-d, q, 1.0), q, q);
+    const double big = fma(-2.0, q, 1.0), small = xd * fma(-xd * xd, 0.3333333333333333, 1.0);
+    return (float)(fabs(xd) < 1e-3 ? small : big);
 }
 
 // WOBS (n_games % 16 == 0): the observation rows of a wavefront's 16 tables are one contiguous
@@ -122,13 +150,15 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     const int wave = threadIdx.x >> 6, q = (threadIdx.x & 63) / LPT;     // wavefront of the workgroup, table of the wavefront
     int32_t* const lw = reinterpret_cast<int32_t*>(smem4) + wave * chunk_lds_dwords(v.obs_size, P_, TPW);
     int32_t* const l_hands = lw + TPW * v.obs_size;                      // [TPW][P_][2]
-    int32_t* const l_prehands = l_hands + TPW * P_ * 2;                  // [TPW][P_]
-    int32_t* const l_prerank = l_prehands + TPW * P_;                    // [TPW][P_]
+    int32_t* const l_prerank = l_hands + TPW * P_ * 2;                   // [TPW][P_]
     float* const l_preeq = reinterpret_cast<float*>(l_prerank + TPW * P_);  // [TPW][3][P_]
     int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + TPW * 3 * P_);  // [TPW][8]: cards at deck position dpos0 + 0..7
     constexpr int DPL = 8 / LPT;                                         // deck-window entries each lane stages
     const int dpos0 = dpos;
     const bool cache_on = (PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board;
+    bool seat_hit[SPL];               // chunk: the cache entry of this lane's seat k was made from the hole cards it holds now
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) seat_hit[k] = false;
     if (MULTI) {
 #pragma unroll
         for (int k = 0; k < SPL; ++k) {
@@ -144,7 +174,8 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 }
             }
             *reinterpret_cast<int2*>(l_hands + (q * P_ + seat) * 2) = h;
-            l_prehands[q * P_ + seat] = ph; l_prerank[q * P_ + seat] = pr;
+            seat_hit[k] = (uint32_t)ph == pack_hand(h.x, h.y) && card_ok(h.x) && card_ok(h.y);        // hole cards are fixed for the episode
+            l_prerank[q * P_ + seat] = pr;
             l_preeq[(q * 3 + 0) * P_ + seat] = e1; l_preeq[(q * 3 + 1) * P_ + seat] = e2; l_preeq[(q * 3 + 2) * P_ + seat] = e3;
         }
         const int32_t* dk = v.decks + (size_t)t * 52;
@@ -283,17 +314,21 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                     const int seat = j + LPT * k;
                     float e = 0.5f;
                     if (seat < A && street) {
-                        int hc0 = h0[k], hc1 = h1[k];
-                        if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
                         bool hit = false;
                         if (cached_board) {       // the cache reads are independent single hops
-                            const uint32_t ph = MULTI ? (uint32_t)l_prehands[q * P_ + seat] : (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
-                            const float pe = MULTI ? l_preeq[(q * 3 + (stage - 1)) * P_ + seat]
-                                                   : ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
-                            hit = ph == pack_hand(hc0, hc1) && card_ok(hc0) && card_ok(hc1);
-                            e = pe;
+                            if (MULTI) {
+                                hit = seat_hit[k];
+                                e = l_preeq[(q * 3 + (stage - 1)) * P_ + seat];
+                            } else {
+                                const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
+                                const float pe = ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
+                                hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
+                                e = pe;
+                            }
                         }
                         if (!hit) {               // the reference's literal seven-gather chain
+                            int hc0 = h0[k], hc1 = h1[k];
+                            if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
                             const float r = (float)walk7(hr, hr_len, hc0, hc1, b0, b1, b2, c5, c6);
                             e = stage == 1 ? __fdiv_rn(__fsub_rn(r, 74359.0f), 749420.0f) : __fdiv_rn(__fsub_rn(r, 4109.0f), 32765.0f);
                             e = fminf(fmaxf(e, 0.0f), 1.0f);
@@ -427,16 +462,20 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                     eligible[k] = seat < A && (status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
                     rank[k] = INT_MIN; payout[k] = 0;
                     if (eligible[k]) {
-                        int hc0 = h0[k], hc1 = h1[k];
-                        if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
                         bool hit = false;
                         if (cached_board) {
-                            const uint32_t ph = MULTI ? (uint32_t)l_prehands[q * P_ + seat] : (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
-                            const int pr = MULTI ? l_prerank[q * P_ + seat] : ldo(v.pre_rank, ROW_OFF(k));
-                            hit = ph == pack_hand(hc0, hc1) && card_ok(hc0) && card_ok(hc1);
-                            rank[k] = pr;
+                            if (MULTI) {
+                                hit = seat_hit[k];
+                                rank[k] = l_prerank[q * P_ + seat];
+                            } else {
+                                const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
+                                hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
+                                rank[k] = ldo(v.pre_rank, ROW_OFF(k));
+                            }
                         }
                         if (!hit) {
+                            int hc0 = h0[k], hc1 = h1[k];
+                            if (MULTI) { const int2 h = hand_of_seat(seat); hc0 = h.x; hc1 = h.y; }
                             rank[k] = walk7(hr, hr_len, hc0, hc1, b0, b1, b2, b3, b4);
                             asm volatile("" : "+v"(rank[k]));      // the chain's last load is waited for HERE, not at the join every table passes
                         }
@@ -515,13 +554,17 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             const int idxm = mod_near(idx, A);
             const int pos = mod_near(idx - button, A);
             // columns 0..12, LPT per pass: lane j writes column LPT*pass + j (an LPT-way select per pass)
-            const int col[13] = {b0, b1, b2, b3, b4, n_h0, n_h1, stage, pos, pot, highest - n_bet, n_stack, n_status};
-#pragma unroll
-            for (int c0 = 0; c0 < 13; c0 += LPT) {
-                int hv = col[c0];
-#pragma unroll
-                for (int jj = 1; jj < LPT; ++jj) if (c0 + jj < 13 && j == jj) hv = col[c0 + jj];
-                if (c0 + j < 13) o[c0 + j] = (float)hv;
+            if (LPT == 4) {
+                const int h0v = j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
+                const int h1v = j == 0 ? b4 : j == 1 ? n_h0 : j == 2 ? n_h1 : stage;
+                const int h2v = j == 0 ? pos : j == 1 ? pot : j == 2 ? highest - n_bet : n_stack;
+                o[j] = (float)h0v; o[4 + j] = (float)h1v; o[8 + j] = (float)h2v;
+                if (j == 0) o[12] = (float)n_status;
+            } else {
+                o[j] = (float)(j == 0 ? b0 : b1); o[2 + j] = (float)(j == 0 ? b2 : b3); o[4 + j] = (float)(j == 0 ? b4 : n_h0);
+                o[6 + j] = (float)(j == 0 ? n_h1 : stage); o[8 + j] = (float)(j == 0 ? pos : pot);
+                o[10 + j] = (float)(j == 0 ? highest - n_bet : n_stack);
+                if (j == 0) o[12] = (float)n_status;
             }
             // opponents: seat (idx+1+k)%A -> columns 13+3k..; seats >= A zero-fill the padding slots
 #pragma unroll
@@ -543,15 +586,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
                 const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
                 const int4* src = reinterpret_cast<const int4*>(l_obs);
-                constexpr int UB = LPT == 4 ? 1 : 5;                             // LDS reads issued together, then the stores: one round trip
-                for (int e0 = wlane; e0 < n4; e0 += 64 * UB) {
-                    int4 piece[UB];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) if (e0 + 64 * u < n4) piece[u] = src[e0 + 64 * u];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u)
-                        if (e0 + 64 * u < n4) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)(e0 + 64 * u) * 16u, piece[u]);
-                }
+                for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
                 if (MULTI) {       // the next step's values must not overtake these reads of the slice
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -591,13 +626,14 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     }
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
         if (board_dirty) {
-            const int bd[5] = {b0, b1, b2, b3, b4};
-#pragma unroll
-            for (int c0 = 0; c0 < 5; c0 += LPT) {
-                int cv = bd[c0];
-#pragma unroll
-                for (int jj = 1; jj < LPT; ++jj) if (c0 + jj < 5 && j == jj) cv = bd[c0 + jj];
-                if (c0 + j < 5) sto(vs.board, bo + (uint32_t)(c0 + j) * 4u, cv);
+            static_assert(LPT == 4 || LPT == 2, "board store");
+            if (LPT == 4) {
+                sto(vs.board, bo + (uint32_t)j * 4u, j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3);
+                if (j == 0) sto(vs.board, bo + 16u, b4);
+            } else {
+                sto(vs.board, bo + (uint32_t)j * 4u, j == 0 ? b0 : b1);
+                sto(vs.board, bo + 8u + (uint32_t)j * 4u, j == 0 ? b2 : b3);
+                if (j == 0) sto(vs.board, bo + 16u, b4);
             }
         }
     }
@@ -632,13 +668,11 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
 }
 
 // ---------------------------------------------------------------- host side
-// lanes per table of a launch: the view's flags can force it (tests, A/B timing); otherwise four for a single step
-// (memory-latency-bound: more wavefronts in flight) and two for a chunk (issue-bound: less replicated scalar work)
-inline int lanes_for(const PulsePokerView& v, bool chunk) {
-    if (v.flags & PULSE_VIEW_LANES2) return 2;
-    if (v.flags & PULSE_VIEW_LANES4) return 4;
-    return chunk ? 2 : 4;
-}
+// lanes per table: four.  (The kernel is written for 2 or 4; two lanes per table -- half the replicated scalar work per
+// table, half the wavefronts -- was measured at 65,536 and 1,048,576 tables and lost both times: a wavefront's step is a
+// dependent chain whose length does not shrink with fewer lanes per table, and with half the wavefronts there is
+// less to overlap it with: 46.9 vs 43.6 us and 553 vs 463 us per 5-step chunk.  Not instantiated.)
+inline int lanes_for(const PulsePokerView&, bool) { return 4; }
 inline dim3 step_grid(const PulsePokerView& v, int lpt) { return dim3((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)); }
 inline bool obs_staging(const PulsePokerView& v, const float* obs_odd, int lpt) {
     return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games % (64 / lpt)) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
@@ -672,13 +706,8 @@ template <uint32_t PH, bool POLICY, bool MULTI>
 void launch_any(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, const ChunkArgs& ca,
                 hipStream_t st) {
     // seats per lane must cover max_players (the observation's padding slots too)
-    if (lanes_for(v, MULTI) == 2) {
-        if (v.max_players <= 10) launch_one<PH, POLICY, 2, 5, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
-        else launch_one<PH, POLICY, 2, 8, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
-    } else {
-        if (v.max_players <= 12) launch_one<PH, POLICY, 4, 3, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
-        else launch_one<PH, POLICY, 4, 4, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
-    }
+    if (v.max_players <= 12) launch_one<PH, POLICY, 4, 3, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
+    else launch_one<PH, POLICY, 4, 4, MULTI>(v, actions, actor_idx, rewards, pa, ca, st);
 }
 
 template <uint32_t PH, bool POLICY>
@@ -709,7 +738,7 @@ struct PulseTimer {
 };
 
 namespace {
-constexpr int kTimedSpan = 4;             // consecutive chunks per event pair: the pair's own queue time (~a fifth of a chunk) is shared by four
+constexpr int kTimedSpan = 8;             // consecutive chunks per event pair (an episode has at most eight): the pair's own queue time is shared
 int timer_begin(PulseTimer* tm, hipStream_t st) {
     if (tm->used >= PulseTimer::kMax) return 0;
     if (tm->used >= tm->created) {

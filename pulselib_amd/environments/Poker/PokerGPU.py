@@ -50,7 +50,7 @@ _ROWS = ("stacks", "current_round_bet", "total_invested", "status")
 _TRACKED = frozenset(_I32_SCALARS + _BOOL_SCALARS + _ROWS + ("hands", "board", "decks", "equities", "obs",
                                                              "w1", "w2", "K", "alpha", "hand_ranks",
                                                              "active_players", "n_players", "n_games", "max_players",
-                                                             "use_eval_cache", "obs_staging", "chunked_rollout", "lanes_per_table"))
+                                                             "use_eval_cache", "obs_staging", "chunked_rollout"))
 
 
 class PokerGPU(_EnvBase):
@@ -99,7 +99,6 @@ class PokerGPU(_EnvBase):
         self.use_eval_cache = True       # reset fills the evaluation cache, steps read it
         self.obs_staging = True          # observations leave as LDS-staged 16-byte bursts (needs n_games % 16 == 0)
         self.chunked_rollout = True      # rollout(): one launch per chunk of steps instead of one per step
-        self.lanes_per_table = None      # None: 4 lanes per table for a single step, 2 for a chunk; or force 2 / 4
         # opt-in: successive steps write their observation into two alternating buffers, so the tensor a step returned
         # stays intact through the NEXT step (a trainer then needs no copy of the pre-step observation).  Off: the
         # reference's single persistent buffer (PokerGPU.py:633).
@@ -230,10 +229,7 @@ class PokerGPU(_EnvBase):
             v = _native.PokerView()
             v.n_games, v.n_players, v.active_players, v.max_players = N, P, A, self.max_players
             v.obs_size, v.hand_ranks_len = self.obs_size, hr.numel()
-            if self.lanes_per_table not in (None, 2, 4):
-                raise ValueError(f"lanes_per_table must be None, 2 or 4, got {self.lanes_per_table!r}")
-            v.flags = ((0 if self.obs_staging else _native.VIEW_NO_OBS_STAGING) | (0 if self.chunked_rollout else _native.VIEW_NO_CHUNK)
-                       | {None: 0, 2: _native.VIEW_LANES2, 4: _native.VIEW_LANES4}[self.lanes_per_table])
+            v.flags = (0 if self.obs_staging else _native.VIEW_NO_OBS_STAGING) | (0 if self.chunked_rollout else _native.VIEW_NO_CHUNK)
             v.hand_ranks = hr.data_ptr()
             for k, p in ptr.items():
                 setattr(v, k, p)

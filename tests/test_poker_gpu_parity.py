@@ -127,7 +127,7 @@ def _seeded_decks(n, seed):
     return (torch.rand((n, 52), generator=g).argsort(dim=1) + 1).to(torch.int32)
 
 
-@pytest.mark.parametrize("variant", ["default", "no_eval_cache", "no_obs_staging", "two_lanes_per_table"])
+@pytest.mark.parametrize("variant", ["default", "no_eval_cache", "no_obs_staging"])
 @pytest.mark.parametrize("N,P,As", [(65536, 10, (10, 7, 2)), (4099, 6, (6, 3)), (4096, 6, (6, 3)), (1, 2, (2,)), (17, 16, (16, 9))])
 def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
     """Config-2 size (65,536 tables, 10 seats) and ragged sizes: every step compared with the oracle -- with the
@@ -141,7 +141,6 @@ def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
     env = _gpu_env(**kw)
     env.use_eval_cache = variant != "no_eval_cache"
     env.obs_staging = variant != "no_obs_staging"
-    env.lanes_per_table = 2 if variant == "two_lanes_per_table" else None        # the single step defaults to four
     ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
     rng = np.random.default_rng(N + P)
     tol = reward_tol(50)
@@ -718,8 +717,7 @@ ROLLOUT_MEMORY = INT_KEYS + ("decks", "equities", "prev_stacks", "prev_invested"
 @pytest.mark.parametrize("N,P,MP", [(4096, 10, 10), (4099, 10, 10), (17, 6, 10), (1, 2, 2), (2048, 16, 16), (1040, 13, 16)],
                          ids=["4096x10", "ragged4099", "17x6", "1x2", "2048x16", "1040x13of16"])
 @pytest.mark.parametrize("dbl", [False, True], ids=["one-obs-buffer", "two-obs-buffers"])
-@pytest.mark.parametrize("lanes", [None, 4, 2], ids=["default-lanes", "4-lanes", "2-lanes"])
-def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl, lanes):
+def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl):
     """pulse_poker_rollout as ONE launch per chunk (state in registers across the steps) against the same call issuing
     one launch per step (PULSE_VIEW_NO_CHUNK): every state tensor, BOTH observation buffers, BOTH reward buffers, both
     done buffers and the actions are bit-identical after every chunk -- chunk lengths 1..19 from odd and even step
@@ -727,7 +725,6 @@ def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl, lan
     kw = dict(n_players=P, max_players=MP, n_games=N, w1=.5, w2=.3, K=100, alpha=50, seed=91, table_id0=7)
     one, per = _gpu_env(**kw), _gpu_env(**kw)
     per.chunked_rollout = False
-    one.lanes_per_table = lanes          # the per-step side keeps its default (four lanes): the two mappings must agree too
     one.double_buffer_obs = per.double_buffer_obs = dbl
     types = ([0, 3, 2, 2, 4, 3, 1, 4, 5, 3, 1, 2, 3, 4, 5, 1])[:P]          # seat 0 external
     rng = np.random.default_rng(5)

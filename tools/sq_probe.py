@@ -34,14 +34,13 @@ import bench  # noqa: E402
 from pulselib_amd.environments.Poker import PokerGPU  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-LANES = int(sys.argv[2]) if len(sys.argv) > 2 else None
+
 dev = torch.device("cuda:0")
 native, q_seat, rot = bench.native_types_for_episode(0)
 actions = torch.zeros(N, dtype=torch.long, device=dev)
 for max_players in (10, 16):
     env = PokerGPU(device=dev, agents=[], n_players=10, max_players=max_players, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
                    K=100, alpha=50, seed=1)
-    env.lanes_per_table = LANES
     for ep, A in enumerate((10, 8, 6, 4)):
         env.reset(options={"active_players": A, "rotation": ep})
         for c in range(7):

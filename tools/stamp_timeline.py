@@ -25,7 +25,6 @@ lib.pulse_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.pulse_debug_set_stamp_buffer.restype = C.c_int
 env = PokerGPU(device=dev, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
                K=100, alpha=50, seed=1)
-env.lanes_per_table = int(sys.argv[3]) if len(sys.argv) > 3 else None
 native, q_seat, rot = bench.native_types_for_episode(0)
 actions = torch.zeros(N, dtype=torch.long, device=dev)
 n_waves = (N * 4 + 63) // 64          # sized for four lanes per table (fewer wavefronts with two)

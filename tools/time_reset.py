@@ -25,8 +25,8 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     dev = torch.device("cuda:0")
     for cache in (True, False):
-        os.environ["PULSE_EVAL_CACHE"] = "1" if cache else "0"
         env = PokerGPU(device=dev, agents=[], n_players=10, max_players=10, n_games=N, seed=3)
+        env.use_eval_cache = cache
         env.reset(options={"active_players": 6})
         decks = env.decks.clone()
         for A in (10, 6, 2):
