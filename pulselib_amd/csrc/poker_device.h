@@ -182,6 +182,11 @@ template <int LPT> __device__ __forceinline__ int grp_imax(int v) {
     if (LPT == 4) v = max(v, dpp_mov<kQuadXor2>(v));
     return v;
 }
+template <int LPT> __device__ __forceinline__ int grp_isum(int v) {
+    v += dpp_mov<kQuadXor1>(v);
+    if (LPT == 4) v += dpp_mov<kQuadXor2>(v);
+    return v;
+}
 
 // x mod A for x that is almost always within one period of [0, A): two conditional corrections,
 // integer division only on the (poked-state) slow path.

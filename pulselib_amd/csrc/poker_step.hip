@@ -16,6 +16,8 @@
 // per chunk, every step still stores its observation / reward / done flag / action (ping-pong buffers, exactly what
 // n single launches leave behind), and the changed state words are written once at the end.  The 130 MB hand-rank
 // table is only touched when a poked state misses the evaluation cache the reset kernel fills.
+#include <type_traits>
+
 #include "poker_device.h"
 
 using namespace pulse_dev;
@@ -88,6 +90,9 @@ __device__ __forceinline__ float tanh_rn(float x) {
     return (float)(fabs(xd) < 1e-3 ? small : big);
 }
 
+// SPL consecutive int32 cells of a row, loaded as one 4-byte-aligned vector (global_load_dwordx3 / x4 take any dword address)
+template <int N_> struct alignas(4) SeatCells { int32_t v[N_]; };
+
 // WOBS (n_games % 16 == 0): the observation rows of a wavefront's 16 tables are one contiguous
 // 16 x obs_size x 4 B block in HBM.  Written column by column they cost thirteen store instructions that each
 // touch sixteen cache lines; with WOBS the lanes drop their values into the wavefront's LDS slice and the
@@ -123,25 +128,68 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     int highest = ldo(v.highest, so), agg = ldo(v.agg, so), acted = ldo(v.acted, so), lrs = ldo(v.last_raise_size, so);
     bool done = ldo(v.is_done, ut) != 0;
     bool dirty = ldo(v.equity_dirty, ut) != 0;
-    int b0 = ldo(v.board, bo), b1 = ldo(v.board, bo + 4), b2 = ldo(v.board, bo + 8), b3 = ldo(v.board, bo + 12), b4 = ldo(v.board, bo + 16);
+    const SeatCells<5> bd_ = ldo(reinterpret_cast<const SeatCells<5>*>(v.board), bo);          // 16 + 4 bytes
+    int b0 = bd_.v[0], b1 = bd_.v[1], b2 = bd_.v[2], b3 = bd_.v[3], b4 = bd_.v[4];
     int stack[SPL], bet[SPL], inv[SPL], status[SPL], h0[SPL], h1[SPL];
     float eq[SPL];
     const uint32_t row0 = __umul24(ut, (uint32_t)P), eq0 = __umul24(ut, (uint32_t)A);
-#define ROW_OFF(k) ((row0 + (uint32_t)(j + LPT * (k))) * 4u)          /* byte offset of (table, seat) in an [N,P] int32 array */
+    // Seats are dealt to the lanes of a table in blocks: lane j owns seats SPL*j .. SPL*j + SPL-1, i.e. SPL consecutive
+    // cells of every [N,P] row -- one 12- or 16-byte load per array instead of SPL dword loads (the prologue is bound by
+    // the number of vector-memory instructions a wavefront issues, not by bytes).  The block of a table's last lane runs
+    // past the row (P = 10: seats 10, 11 = the next table's first cells: loaded, masked); where it would run past the
+    // ARRAY (the last table) the cells are loaded one by one.
+#define SEAT(k) (SPL * j + (k))
+#define ROW_OFF(k) ((row0 + (uint32_t)SEAT(k)) * 4u)                   /* byte offset of (table, seat) in an [N,P] int32 array */
+    const uint32_t cell0 = row0 + (uint32_t)(SPL * j), ecell0 = eq0 + (uint32_t)(SPL * j);     // this lane's first cell
+    const bool vec_ok = cell0 + (uint32_t)SPL <= __umul24((uint32_t)v.n_games, (uint32_t)P) &&
+                        ecell0 + (uint32_t)SPL <= __umul24((uint32_t)v.n_games, (uint32_t)A);   // (implies the same for hands and pre_eq)
+    // VEC = std::true_type: one vector load; std::false_type: cell by cell.  `limit` = seats that exist in the row.
+    auto load_cells = [&](auto VEC, const int32_t* base, uint32_t first_cell, int limit, int (&out)[SPL], int fill) {
+        SeatCells<SPL> c;
+        if (decltype(VEC)::value) c = ldo(reinterpret_cast<const SeatCells<SPL>*>(base), first_cell * 4u);
+        else {
 #pragma unroll
-    for (int k = 0; k < SPL; ++k) {
-        const int seat = j + LPT * k;
-        stack[k] = 0; bet[k] = 0; inv[k] = 0; status[k] = PULSE_SITOUT; h0[k] = -1; h1[k] = -1; eq[k] = 0.5f;
-        if (seat < P) {
-            stack[k] = ldo(v.stacks, ROW_OFF(k)); bet[k] = ldo(v.current_round_bet, ROW_OFF(k));
-            inv[k] = ldo(v.total_invested, ROW_OFF(k)); status[k] = ldo(v.status, ROW_OFF(k));
-            if (!MULTI) {          // a chunk reads hole cards where it needs them (they never change inside an episode)
-                const int2 h = ldo(reinterpret_cast<const int2*>(v.hands), ROW_OFF(k) * 2u);
-                h0[k] = h.x; h1[k] = h.y;
+            for (int k = 0; k < SPL; ++k) c.v[k] = SEAT(k) < limit ? ldo(base, (first_cell + (uint32_t)k) * 4u) : fill;
+        }
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) out[k] = SEAT(k) < limit ? c.v[k] : fill;
+    };
+    auto load_hands = [&](auto VEC, int (&o0)[SPL], int (&o1)[SPL]) {
+        SeatCells<2 * SPL> c;
+        if (decltype(VEC)::value) c = ldo(reinterpret_cast<const SeatCells<2 * SPL>*>(v.hands), cell0 * 8u);
+        else {
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                int2 h = make_int2(-1, -1);
+                if (SEAT(k) < P) h = ldo(reinterpret_cast<const int2*>(v.hands), ROW_OFF(k) * 2u);
+                c.v[2 * k] = h.x; c.v[2 * k + 1] = h.y;
             }
         }
-        if (seat < A) eq[k] = ldo(v.equities, (eq0 + (uint32_t)seat) * 4u);
-    }
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) { o0[k] = SEAT(k) < P ? c.v[2 * k] : -1; o1[k] = SEAT(k) < P ? c.v[2 * k + 1] : -1; }
+    };
+    const bool cache_on = (PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board;
+    int ph_[SPL], pr_[SPL], e1_[SPL], e2_[SPL], e3_[SPL];            // chunk only: the evaluation cache's rows (staged in LDS below)
+    auto load_rows = [&](auto VEC) {
+        load_cells(VEC, v.stacks, cell0, P, stack, 0); load_cells(VEC, v.current_round_bet, cell0, P, bet, 0);
+        load_cells(VEC, v.total_invested, cell0, P, inv, 0); load_cells(VEC, v.status, cell0, P, status, PULSE_SITOUT);
+        int ei[SPL];
+        load_cells(VEC, reinterpret_cast<const int32_t*>(v.equities), ecell0, A, ei, 0x3f000000 /* 0.5f */);
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) eq[k] = __int_as_float(ei[k]);
+        load_hands(VEC, h0, h1);          // (a chunk keeps them in LDS: they never change inside an episode)
+        if (MULTI) {
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) { ph_[k] = 0; pr_[k] = 0; e1_[k] = 0; e2_[k] = 0; e3_[k] = 0; }
+            if (cache_on) {
+                load_cells(VEC, v.pre_hands, cell0, P, ph_, 0); load_cells(VEC, v.pre_rank, cell0, P, pr_, 0);
+                const int32_t* pe = reinterpret_cast<const int32_t*>(v.pre_eq);     // [N,3,P]: three rows of P per table
+                const uint32_t c0 = __umul24(ut * 3u, (uint32_t)P) + (uint32_t)(SPL * j);
+                load_cells(VEC, pe, c0, P, e1_, 0); load_cells(VEC, pe, c0 + (uint32_t)P, P, e2_, 0); load_cells(VEC, pe, c0 + 2u * (uint32_t)P, P, e3_, 0);
+            }
+        }
+    };
+    if (vec_ok) load_rows(std::true_type{}); else load_rows(std::false_type{});
     // ---- chunk only: the read-only rows the steps consult (hole cards, the evaluation cache, the next cards of the deck)
     // are staged in the wavefront's LDS slice ONCE.  A global load inside the step loop would have to be waited for
     // with s_waitcnt vmcnt, which counts stores too -- i.e. for every observation / reward / done store of the
@@ -155,28 +203,18 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + TPW * 3 * P_);  // [TPW][8]: cards at deck position dpos0 + 0..7
     constexpr int DPL = 8 / LPT;                                         // deck-window entries each lane stages
     const int dpos0 = dpos;
-    const bool cache_on = (PH & (PULSE_PH_EQUITY | PULSE_PH_SHOWDOWN)) && v.pre_board;
     bool seat_hit[SPL];               // chunk: the cache entry of this lane's seat k was made from the hole cards it holds now
 #pragma unroll
     for (int k = 0; k < SPL; ++k) seat_hit[k] = false;
     if (MULTI) {
 #pragma unroll
         for (int k = 0; k < SPL; ++k) {
-            const int seat = j + LPT * k;
-            int2 h = make_int2(-1, -1);
-            int ph = 0, pr = 0; float e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;
-            if (seat < P) {
-                h = ldo(reinterpret_cast<const int2*>(v.hands), ROW_OFF(k) * 2u);
-                if (cache_on) {
-                    ph = ldo(v.pre_hands, ROW_OFF(k)); pr = ldo(v.pre_rank, ROW_OFF(k));
-                    const uint32_t e0 = (__umul24(ut * 3u, (uint32_t)P) + (uint32_t)seat) * 4u, es = (uint32_t)P * 4u;
-                    e1 = ldo(v.pre_eq, e0); e2 = ldo(v.pre_eq, e0 + es); e3 = ldo(v.pre_eq, e0 + 2u * es);
-                }
-            }
-            *reinterpret_cast<int2*>(l_hands + (q * P_ + seat) * 2) = h;
-            seat_hit[k] = (uint32_t)ph == pack_hand(h.x, h.y) && card_ok(h.x) && card_ok(h.y);        // hole cards are fixed for the episode
-            l_prerank[q * P_ + seat] = pr;
-            l_preeq[(q * 3 + 0) * P_ + seat] = e1; l_preeq[(q * 3 + 1) * P_ + seat] = e2; l_preeq[(q * 3 + 2) * P_ + seat] = e3;
+            const int seat = SEAT(k);
+            *reinterpret_cast<int2*>(l_hands + (q * P_ + seat) * 2) = make_int2(h0[k], h1[k]);
+            seat_hit[k] = (uint32_t)ph_[k] == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);        // hole cards are fixed for the episode
+            l_prerank[q * P_ + seat] = pr_[k];
+            l_preeq[(q * 3 + 0) * P_ + seat] = __int_as_float(e1_[k]); l_preeq[(q * 3 + 1) * P_ + seat] = __int_as_float(e2_[k]);
+            l_preeq[(q * 3 + 2) * P_ + seat] = __int_as_float(e3_[k]);
         }
         const int32_t* dk = v.decks + (size_t)t * 52;
 #pragma unroll
@@ -237,8 +275,8 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     int prev_stack = 0, prev_invested = 0;
 
     // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
-#define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << (j + LPT * k); return grp_or<LPT>(m_); }())
-#define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)grp_or<LPT>(r_); }())
+#define SEAT_BITS(expr) ([&]() { uint32_t m_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) m_ |= (uint32_t)((expr) ? 1u : 0u) << SEAT(k); return grp_or<LPT>(m_); }())
+#define SEAT_PICK(arr, seat_) ([&]() { uint32_t r_ = 0; _Pragma("unroll") for (int k = 0; k < SPL; ++k) r_ |= SEAT(k) == (seat_) ? (uint32_t)(arr)[k] : 0u; return (int)grp_or<LPT>(r_); }())
 
     STAMP(1);   // loads issued
     // The seat to act, as every lane of the table sees it: status / stack / round bet / hole cards.  Nothing changes
@@ -311,7 +349,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 const bool cached_board = street && board_matches(pre_tag, stage + 2, b0, b1, b2, b3, b4);
 #pragma unroll
                 for (int k = 0; k < SPL; ++k) {
-                    const int seat = j + LPT * k;
+                    const int seat = SEAT(k);
                     float e = 0.5f;
                     if (seat < A && street) {
                         bool hit = false;
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
         {
             uint32_t r_ = 0;
 #pragma unroll
-            for (int k = 0; k < SPL; ++k) r_ |= (j + LPT * k) == actor ? __float_as_uint(eq[k]) : 0u;
+            for (int k = 0; k < SPL; ++k) r_ |= SEAT(k) == actor ? __float_as_uint(eq[k]) : 0u;
             e_actor = __uint_as_float(grp_or<LPT>(r_));
             if (actor >= LPT * SPL) e_actor = 0.5f;
         }
@@ -382,7 +420,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 bet_dirty = true;
 #pragma unroll
                 for (int k = 0; k < SPL; ++k)
-                    if (j + LPT * k == (idx & 15)) { stack[k] = n_stack; bet[k] = n_bet; inv[k] += n_inv_add; status[k] = n_status; cells_dirty |= 1u << k; }
+                    if (SEAT(k) == (idx & 15)) { stack[k] = n_stack; bet[k] = n_bet; inv[k] += n_inv_add; status[k] = n_status; cells_dirty |= 1u << k; }
             }
         }
 
@@ -437,7 +475,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             if (newly_done && contenders == 1) {
                 const int survivor = __ffs((int)cont_bits) - 1;
 #pragma unroll
-                for (int k = 0; k < SPL; ++k) if (j + LPT * k == survivor) { stack[k] += pot; cells_dirty |= 1u << k; }
+                for (int k = 0; k < SPL; ++k) if (SEAT(k) == survivor) { stack[k] += pot; cells_dirty |= 1u << k; }
                 pot = 0; bet_dirty = true;
             }
         }
@@ -458,7 +496,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 const bool cached_board = board_matches(pre_tag, 5, b0, b1, b2, b3, b4);
 #pragma unroll
                 for (int k = 0; k < SPL; ++k) {
-                    const int seat = j + LPT * k;
+                    const int seat = SEAT(k);
                     eligible[k] = seat < A && (status[k] == PULSE_ACTIVE || status[k] == PULSE_ALLIN);
                     rank[k] = INT_MIN; payout[k] = 0;
                     if (eligible[k]) {
@@ -486,15 +524,15 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 for (int l = 0; l < A; ++l) {
                     int lv = INT_MAX;
 #pragma unroll
-                    for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] > prev_level) lv = min(lv, inv[k]);
+                    for (int k = 0; k < SPL; ++k) if (SEAT(k) < A && inv[k] > prev_level) lv = min(lv, inv[k]);
                     const int level = grp_imin<LPT>(lv);
                     if (level == INT_MAX) break;
-                    const int n_contrib = __popc(SEAT_BITS((j + LPT * k) < A && inv[k] >= level));
+                    const int n_contrib = __popc(SEAT_BITS(SEAT(k) < A && inv[k] >= level));
                     int bl = INT_MIN;
 #pragma unroll
-                    for (int k = 0; k < SPL; ++k) if ((j + LPT * k) < A && inv[k] >= level && eligible[k]) bl = max(bl, rank[k]);
+                    for (int k = 0; k < SPL; ++k) if (SEAT(k) < A && inv[k] >= level && eligible[k]) bl = max(bl, rank[k]);
                     const int best = grp_imax<LPT>(bl);
-                    const uint32_t win_bits = SEAT_BITS((j + LPT * k) < A && inv[k] >= level && eligible[k] && rank[k] == best);
+                    const uint32_t win_bits = SEAT_BITS(SEAT(k) < A && inv[k] >= level && eligible[k] && rank[k] == best);
                     const int n_win = __popc(win_bits);
                     if (n_win > 0) {
                         const int layer_pot = (level - prev_level) * n_contrib;
@@ -502,7 +540,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                         const int first_win = __ffs((int)win_bits) - 1;
 #pragma unroll
                         for (int k = 0; k < SPL; ++k)
-                            if ((win_bits >> (j + LPT * k)) & 1u) payout[k] += share + ((j + LPT * k) == first_win ? rem : 0);
+                            if ((win_bits >> SEAT(k)) & 1u) payout[k] += share + (SEAT(k) == first_win ? rem : 0);
                     }
                     prev_level = level;
                 }
@@ -569,7 +607,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             // opponents: seat (idx+1+k)%A -> columns 13+3k..; seats >= A zero-fill the padding slots
 #pragma unroll
             for (int k = 0; k < SPL; ++k) {
-                const int seat = j + LPT * k;
+                const int seat = SEAT(k);
                 if (seat < v.max_players && seat != idxm) {
                     int slot; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
                     if (seat < A) { slot = seat - idxm - 1; if (slot < 0) slot += A; f0 = (float)stack[k]; f1 = (float)status[k]; f2 = (float)bet[k]; }
@@ -616,7 +654,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     const PulsePokerView& vs = MULTI ? *reinterpret_cast<const PulsePokerView*>(kernarg) : v;   // the view is the first kernel argument
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
-        const int seat = j + LPT * k;
+        const int seat = SEAT(k);
         if (seat < P && ((cells_dirty >> k) & 1u)) {
             if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(vs.stacks, ROW_OFF(k), stack[k]);
             if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(vs.current_round_bet, ROW_OFF(k), bet[k]);
@@ -665,6 +703,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
 #undef SEAT_BITS
 #undef SEAT_PICK
 #undef ROW_OFF
+#undef SEAT
 }
 
 // ---------------------------------------------------------------- host side

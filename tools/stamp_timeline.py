@@ -31,7 +31,8 @@ n_waves = (N * 4 + 63) // 64          # sized for four lanes per table (fewer wa
 buf = torch.zeros((n_waves, 16), dtype=torch.int64, device=dev)
 names = ["launch->start", "issue loads", "wait loads+pick actor", "policy", "equities", "execute+masks", "advance/deal", "payouts",
          "reward", "obs stores", "state stores", "drain stores"]
-for A, warm in ((8, 6), (8, 20), (6, 33)):
+WARMS = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else None
+for A, warm in ([(10, w) for w in WARMS] if WARMS else ((8, 6), (8, 20), (6, 33))):
     env.reset(options={"active_players": A})
     env.rollout(native, actions, warm, 100)
     torch.cuda.synchronize()
