@@ -114,6 +114,12 @@ int pulse_handranks_generate(int32_t* out, int n_threads);
 int pulse_poker_eval_hands(const int32_t* hand_ranks, int32_t hand_ranks_len, const int32_t* cards,
                            int32_t n_hands, int32_t n_cards, int32_t flop_double, int32_t* out, void* stream);
 
+/* The closed-form evaluator the reset kernel fills its evaluation cache with (csrc/hand_eval_device.h: the evaluator
+ * the table is generated from), alone, for the tests that hold it to the table walk: cards device
+ * int32[n_hands,n_cards] of 5..7 DISTINCT cards in 1..52; out[i] = category << 12 | index, what the walk of
+ * PokerGPU.py:437-444 returns for them (n_cards 5 / 6: HR[p] after the last card).  Diagnostic, not drop-in surface. */
+int pulse_poker_eval_closed_form(const int32_t* cards, int32_t n_hands, int32_t n_cards, int32_t* out, void* stream);
+
 /* PokerGPU.step (PokerGPU.py:527-633), one fused launch.  actions device int64[N] (any value; <0 =
  * no-op, >12 = raise of 0 as in the reference's masks), rewards device fp32[N] out. */
 int pulse_poker_step(const PulsePokerView* v, const int64_t* actions, float* rewards, void* stream);
@@ -191,7 +197,7 @@ int pulse_timer_destroy(void* timer);
 /* The trainer's episode stop rule (scripts/Poker/trainGPU.py:27-33,99: every 5th step, more than `threshold` of the
  * tables done ends the episode) without its blocking read, for one GPU or for one process per GPU.
  * A "check point" is one evaluation of the rule.  pulse_poker_rollout (or submit) leaves the check point's done
- * tables counted per wavefront on the device; the NEXT launch on that stream sums them with one extra workgroup and
+ * tables counted per wavefront on the device; the NEXT launch on that stream sums them in its first workgroup (before that workgroup's own tables) and
  * writes the count + a sequence number into coherent pinned host memory, which decide()/counts() poll -- no event,
  * no second stream, no kernel of its own between the steps' launches, and the host sees a count a microsecond after
  * it exists.  decide() answers for the check point submitted `lag` check points before the newest one: a FIXED lag,

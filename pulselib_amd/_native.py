@@ -86,6 +86,7 @@ SYMBOLS = {
     "pulse_last_error": (C.c_char_p, []),
     "pulse_handranks_generate": (C.c_int, [_P, C.c_int]),
     "pulse_poker_eval_hands": (C.c_int, [_P, _I32, _P, _I32, _I32, _I32, _P, _P]),
+    "pulse_poker_eval_closed_form": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "pulse_poker_step": (C.c_int, [_P, _P, _P, _P]),
     "pulse_poker_phases": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
     "pulse_poker_reset": (C.c_int, [_P, _P, _P]),

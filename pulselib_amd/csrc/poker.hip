@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "poker_device.h"
+#include "hand_eval_device.h"
 
 using namespace pulse_dev;
 
@@ -44,6 +45,16 @@ __global__ __launch_bounds__(kBlock) void poker_eval_kernel(const int32_t* __res
         p = walk7(hr, len, c[0], c[1], c[2], c[3], c[4], c5, c6);
     }
     out[i] = p;
+}
+
+// closed-form evaluator alone (tests): value of n_cards (5..7) distinct valid cards per hand
+__global__ __launch_bounds__(kBlock) void poker_eval_closed_form_kernel(const int32_t* __restrict__ cards, int n_hands, int n_cards,
+                                                                       int32_t* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_hands) return;
+    HandAcc acc;
+    for (int k = 0; k < n_cards; ++k) hand_add(acc, cards[(size_t)i * n_cards + k]);
+    out[i] = hand_value(acc);
 }
 
 // ---------------------------------------------------------------- reset (PokerGPU.py:73-157)
@@ -136,16 +147,19 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         const int32_t* __restrict__ hr = v.hand_ranks;
         const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
         if (valid && inA) {
-            int p3 = 53;
-            p3 = hr_at(hr, hr_len, p3 + f0); p3 = hr_at(hr, hr_len, p3 + f1); p3 = hr_at(hr, hr_len, p3 + f2);
-            const int p4 = hr_at(hr, hr_len, p3 + f3);
-            const int p5 = hr_at(hr, hr_len, p4 + f4);
-            // three independent chains, issued level by level (unconditional loads: no branch between them)
-            const int a1 = hr_at_nb(hr, hr_len, p3 + h0), b1 = hr_at_nb(hr, hr_len, p4 + h0), c1 = hr_at_nb(hr, hr_len, p5 + h0);
-            const int q5 = hr_at_nb(hr, hr_len, a1 + h1), q6 = hr_at_nb(hr, hr_len, b1 + h1), r7 = hr_at_nb(hr, hr_len, c1 + h1);
-            const int a3 = hr_at_nb(hr, hr_len, q5);
-            const float vt = (float)hr_at_nb(hr, hr_len, q6);                               // :500
-            const float vf = (float)hr_at_nb(hr, hr_len, a3);                               // :521
+            // For distinct valid cards the table walk returns the closed-form hand value (hand_eval_device.h -- the
+            // evaluator the table is generated from), so the three streets are computed instead of gathered: flop =
+            // HR[value of the 5 cards] (:521 reads the table once more at the value itself: its hot first 150 KB),
+            // turn = value of the 6 cards (:500), river / showdown = value of the 7 (:437-444).
+            HandAcc acc;
+            hand_add(acc, h0); hand_add(acc, h1); hand_add(acc, f0); hand_add(acc, f1); hand_add(acc, f2);
+            const int v5 = hand_value(acc);
+            hand_add(acc, f3);
+            const int v6 = hand_value(acc);
+            hand_add(acc, f4);
+            const int r7 = hand_value(acc);
+            const float vf = (float)hr_at_nb(hr, hr_len, v5);                               // :521
+            const float vt = (float)v6;                                                     // :500
             float ef = __fdiv_rn(__fsub_rn(vf, 74359.0f), 749420.0f);                       // :523
             float et = __fdiv_rn(__fsub_rn(vt, 4109.0f), 32765.0f);                         // :502
             float er = __fdiv_rn(__fsub_rn((float)r7, 4109.0f), 32765.0f);                  // :481
@@ -343,6 +357,14 @@ int pulse_poker_eval_hands(const int32_t* hand_ranks, int32_t hand_ranks_len, co
     hipLaunchKernelGGL(poker_eval_kernel, dim3((n_hands + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
                        hand_ranks, (uint32_t)hand_ranks_len, cards, n_hands, n_cards, flop_double, out);
     return pulse::finish_launch("pulse_poker_eval_hands");
+}
+
+int pulse_poker_eval_closed_form(const int32_t* cards, int32_t n_hands, int32_t n_cards, int32_t* out, void* stream) {
+    if (!cards || !out || n_hands < 0 || n_cards < 5 || n_cards > 7) return pulse::fail(PULSE_EINVAL, "pulse_poker_eval_closed_form: bad argument");
+    if (n_hands == 0) return 0;
+    hipLaunchKernelGGL(poker_eval_closed_form_kernel, dim3((n_hands + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       cards, n_hands, n_cards, out);
+    return pulse::finish_launch("pulse_poker_eval_closed_form");
 }
 
 int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_t* mask, int32_t n, int64_t* stats,

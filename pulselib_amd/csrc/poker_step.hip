@@ -32,7 +32,7 @@ __host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int 
 struct PolicyArgs {
     uint64_t types_packed, seed, step_counter, table_id0;
     uint32_t* wave_done;                   // nullptr, or one word per wavefront of the launch: tables done after the last step
-    // the PREVIOUS check point's wavefront counts, summed and published to the host by one extra workgroup of this launch
+    // the PREVIOUS check point's wavefront counts, summed and published to the host by workgroup 0 of this launch, before its own tables
     const uint32_t* carry_partials; int carry_n; long long* carry_host; long long carry_seq;
 };
 struct ChunkArgs {                         // MULTI only: the odd steps' output buffers and the number of steps
@@ -108,9 +108,12 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     constexpr int TPW = 64 / LPT;                                        // tables per wavefront
     static_assert(!MULTI || (POLICY && PH == PULSE_PH_STEP), "a chunk is fused policy + full step");
     extern __shared__ int4 smem4[];
-    if (POLICY && pa.carry_n > 0 && blockIdx.x == gridDim.x - 1) {       // the extra workgroup: the stop rule's previous check point
+    if (POLICY && pa.carry_n > 0 && blockIdx.x == 0) {
+        // The stop rule's previous check point: workgroup 0 sums its per-wavefront counts and publishes the total to
+        // the host BEFORE its own tables.  (A separate last workgroup did this in the first version; at 65,536 tables
+        // the grid fills the chip exactly, so that workgroup only got a slot when the first one retired and the host
+        // learned the count ~35 us later than it could -- too late to keep the queue fed at an episode boundary.)
         sum_and_publish(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
-        return;
     }
     const int gt = blockIdx.x * kBlock + threadIdx.x;
     const int t = gt / LPT;
@@ -722,7 +725,6 @@ void launch_one(const PulsePokerView& v, int64_t* actions, const int32_t* actor_
                 hipStream_t st) {
     dim3 grid = step_grid(v, LPT);
     const dim3 block(kBlock);
-    if (POLICY && pa.carry_n > 0) grid.x += 1;       // + the workgroup that publishes the stop rule's previous check point
     constexpr int TPW = 64 / LPT;
     const bool wobs = (PH & PULSE_PH_OBS) && (MULTI || PH == PULSE_PH_STEP) && obs_staging(v, MULTI ? ca.obs_odd : nullptr, LPT);
     const size_t lds = MULTI ? sizeof(int32_t) * (size_t)(kBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, LPT * SPL, TPW)

@@ -15,8 +15,8 @@ int fail_hip(int hip_error, const char* what);
 
 // stoprule.hip: a check point's partial done-counts (one uint32 per wavefront / workgroup) are written in stream order
 // into the slot `claim` hands out.  Their sum is published to the host by the NEXT launch on that stream: `claim` also
-// returns the previous check point's counts as a `carry`, which that launch sums and publishes with one extra
-// workgroup (no event, no second stream, no kernel of its own on the steps' stream).
+// returns the previous check point's counts as a `carry`, which that launch sums and publishes in its first
+// workgroup, ahead of that workgroup's tables (no event, no second stream, no kernel of its own on the steps' stream).
 struct StopRuleCarry {
     const uint32_t* partials;     // nullptr: nothing to carry
     int n;

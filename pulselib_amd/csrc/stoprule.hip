@@ -251,7 +251,7 @@ int flush(PulseStopRule* h, long long c) {
 namespace pulse {
 
 // Slot the check point about to be submitted will use, and -- if the previous check point has not been scheduled for
-// publication yet -- what the launch about to be enqueued shall sum and publish on its way (an extra workgroup of it).
+// publication yet -- what the launch about to be enqueued shall sum and publish on its way (workgroup 0 of it, first thing).
 int stoprule_claim(PulseStopRule* h, int n_partials, uint32_t** partials_out, StopRuleCarry* carry) {
     if (n_partials <= 0 || n_partials > h->max_partials) return fail(PULSE_EINVAL, "stop rule: too many partial counts for this handle");
     const int slot = (int)(h->submitted % kSlots);

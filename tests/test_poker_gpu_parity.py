@@ -185,6 +185,34 @@ def test_eval_hands_kernel_matches_golden_vectors(golden_dir):
         np.testing.assert_array_equal(out.cpu().numpy(), vec[key], err_msg=key)
 
 
+@pytest.mark.parametrize("n_cards", [5, 6, 7])
+def test_closed_form_evaluator_equals_the_table_walk(golden_dir, n_cards):
+    """The reset kernel fills the evaluation cache with the closed-form evaluator (csrc/hand_eval_device.h) instead of
+    walking the table: held here to the walk on 2,000,000 random hands per card count and on the golden vectors
+    (which come from the table the reference's own constants pin, tests/test_handranks.py)."""
+    from pulselib_amd import _native, handranks
+    table = handranks.device_table(DEV)
+    lib = _native.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu")
+    g.manual_seed(100 + n_cards)
+    n = 2_000_000
+    cards = (torch.rand((n, 52), generator=g).argsort(dim=1)[:, :n_cards] + 1).to(torch.int32).to(DEV).contiguous()
+    vec = np.load(golden_dir / "handranks_vectors.npz")
+    gold = torch.from_numpy(vec["hands"].astype(np.int32))[:, :n_cards].contiguous().to(DEV)
+    for batch, want in ((cards, None), (gold, vec[f"rank{n_cards}"])):
+        walk = torch.empty(batch.shape[0], dtype=torch.int32, device=DEV)
+        closed = torch.empty_like(walk)
+        _native.check(lib.pulse_poker_eval_hands(table.data_ptr(), table.numel(), batch.data_ptr(), batch.shape[0], n_cards, 0,
+                                                 walk.data_ptr(), stream))
+        _native.check(lib.pulse_poker_eval_closed_form(batch.data_ptr(), batch.shape[0], n_cards, closed.data_ptr(), stream))
+        assert torch.equal(walk, closed), f"{int((walk != closed).sum())} of {batch.shape[0]} {n_cards}-card hands differ"
+        if want is not None:
+            np.testing.assert_array_equal(closed.cpu().numpy(), want)
+    cats = torch.bincount((closed if want is None else walk) >> 12, minlength=10)
+    assert int(cats[0]) == 0
+
+
 def test_device_table_digest_matches_golden(golden_dir):
     import hashlib
     from pulselib_amd import handranks
