@@ -168,7 +168,8 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
             pe[s] = ef; pe[P + s] = et; pe[2 * P + s] = er;
             v.pre_rank[row] = r7;
         }
-        if (seat) v.pre_hands[row] = (valid && inA) ? (int32_t)pack_hand(h0, h1) : 0;
+        // hole-card tag + the scripted players' class of the hand (poker_device.h: hand_class), both fixed for the episode
+        if (seat) v.pre_hands[row] = (valid && inA) ? (int32_t)(pack_hand(h0, h1) | hand_class(h0, h1) << kClsShift) : 0;
         if (s == 0) v.pre_board[t] = valid ? (int32_t)(pack_board(f0, f1, f2, f3, f4) | kPreBoardValid) : 0;
     }
     const int button = o.first ? 0 : pymod(v.button[t] + 1, A);                         // :121

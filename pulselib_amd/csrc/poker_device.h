@@ -90,33 +90,50 @@ __device__ __forceinline__ PolicyDraw policy_draw(const U4& call, uint64_t step)
 
 // ---------------------------------------------------------------- scripted opponents
 // environments/Poker/Player.py:79-176 + utils.py:121; c1,c2 = hole cards 1..52, pot = obs col 9.
-// Branch-free: the tables of a wavefront are played by different types, so a switch would run every case anyway
-// (and pay a branch for each).  Every type reduces to `raise ? base + randint(n) : otherwise`, one multiply for the draw.
-__device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot, const PolicyDraw& rnd) {
+// Everything the four hand-written players derive from the two hole cards alone is a handful of predicates -- the
+// hand's CLASS, fixed for the episode like the cards: computed once (by the reset kernel into the spare bits of the
+// evaluation cache's hole-card tag, or at a chunk's start) instead of at every step; what is left per step is the
+// type's row of the table below, small_ball's pot thresholds and the two draws.
+constexpr uint32_t kClsHhRaise = 1u << 0;     // heuristic_hands raises: pair / a king or ace, not both cards low   (Player.py:85-102)
+constexpr uint32_t kClsTaRaise = 1u << 1;     // tight_aggressive raises                                              (:112-124)
+constexpr uint32_t kClsLpCall = 1u << 2;      // loose_passive calls (and raises when its coin says so)              (:134-149)
+constexpr uint32_t kClsSbStrong = 1u << 3;    // small_ball raises unless the pot rule folds                          (:159-174)
+constexpr uint32_t kClsSbLow6 = 1u << 4;      // both cards below rank 6 (small_ball folds into pots > 30)
+constexpr uint32_t kClsSbLow9 = 1u << 5;      // both cards below rank 9 (small_ball folds into pots > 80)
+constexpr uint32_t kClsTaCall = 1u << 6;      // tight_aggressive does not fold
+constexpr int kClsShift = 13;                 // where the class sits in a pre_hands word (above the 13-bit hole-card tag)
+__device__ __forceinline__ uint32_t hand_class(int c1, int c2) {
     const int r1 = pymod(c1, 13), r2 = pymod(c2, 13);
     const int d = r1 > r2 ? r1 - r2 : r2 - r1;
     const bool pair = r1 == r2;
     const bool strong = pair || (r1 >= 10 && r2 > 5) || (r2 >= 10 && r1 > 5);          // tight_aggressive / small_ball raise hands
-    // heuristic_hands (Player.py:85-102): fold (0) unless pair / a king or ace -> 2 + randint(0, 9)
     const bool hh_fold = r1 < 8 && r2 < 8;
     const bool hh_raise = (pair || r1 >= 10 || r2 >= 10) && !hh_fold;
-    // tight_aggressive (:112-124): call (1), fold small unconnected, raise 2 + randint(5, 9)
     const bool ta_fold = r1 < 7 && r2 < 7 && d > 5;
-    const bool ta_raise = strong && !ta_fold;
-    // loose_passive (:134-149): fold (0), call (1) premium hands, of those rand() > .9 raises 2 + randint(0, 4)
     const bool lp_fold = r1 <= 4 && r2 <= 4 && d > 9;
     const bool lp_call = ((pair && r1 > 8) || (r1 >= 11 && r2 > 9) || (r2 >= 11 && r1 > 9)) && !lp_fold;
-    const bool lp_raise = rand_unit(rnd.coin) > 0.9f && lp_call;
-    // small_ball (:159-174): fold (0) weak hands into big pots, raise 2 + randint(0, 3)
-    const bool sb_fold = (r1 < 6 && r2 < 6 && pot > 30) || (r1 < 9 && r2 < 9 && pot > 80);
-    const bool sb_raise = strong && !sb_fold;
+    return (hh_raise ? kClsHhRaise : 0u) | (strong && !ta_fold ? kClsTaRaise : 0u) | (lp_call ? kClsLpCall : 0u) |
+           (strong ? kClsSbStrong : 0u) | (r1 < 6 && r2 < 6 ? kClsSbLow6 : 0u) | (r1 < 9 && r2 < 9 ? kClsSbLow9 : 0u) |
+           (!ta_fold ? kClsTaCall : 0u);
+}
+// Branch-free: the tables of a wavefront are played by different types, so a switch would run every case anyway
+// (and pay a branch for each).  Every type reduces to `raise ? base + randint(n) : otherwise`, one multiply for the draw.
+__device__ __forceinline__ int scripted_action_cls(int type, uint32_t cls, int pot, const PolicyDraw& rnd) {
     const bool t_rand = type == PULSE_AGENT_RANDOM, t_hh = type == PULSE_AGENT_HEURISTIC_HANDS, t_ta = type == PULSE_AGENT_TIGHT_AGGRESSIVE,
                t_lp = type == PULSE_AGENT_LOOSE_PASSIVE, t_sb = type == PULSE_AGENT_SMALL_BALL;
-    const bool draws = t_rand || (t_hh && hh_raise) || (t_ta && ta_raise) || (t_lp && lp_raise) || (t_sb && sb_raise);
+    // types 2..5 raise on class bits 0..3 (in that order), subject to loose_passive's coin and small_ball's pot rule
+    const uint32_t slot = (uint32_t)(type - PULSE_AGENT_HEURISTIC_HANDS);
+    const bool cand = slot < 4u && ((cls >> (slot & 3u)) & 1u) != 0u;
+    const bool sb_fold = ((cls & kClsSbLow6) && pot > 30) || ((cls & kClsSbLow9) && pot > 80);
+    const bool lp_raise = rand_unit(rnd.coin) > 0.9f;
+    const bool draws = t_rand || (cand && (!t_lp || lp_raise) && (!t_sb || !sb_fold));
     const int n = t_rand ? 13 : t_hh ? 9 : t_sb ? 3 : 4;                                 // randint range (utils.py:121: randint(0, 13))
     const int base = t_rand ? 0 : t_ta ? 7 : 2;
-    const int otherwise = (t_ta && !ta_fold) || (t_lp && lp_call) ? 1 : 0;               // the type's action when it does not raise
+    const int otherwise = (t_ta && (cls & kClsTaCall)) || (t_lp && (cls & kClsLpCall)) ? 1 : 0;   // the type's action when it does not raise
     return draws ? base + rand_below(rnd.pick, n) : otherwise;
+}
+__device__ __forceinline__ int scripted_action(int type, int c1, int c2, int pot, const PolicyDraw& rnd) {
+    return scripted_action_cls(type, hand_class(c1, c2), pot, rnd);
 }
 
 // 32-bit byte-offset addressing: base pointers are wave-uniform (SGPR pair) and every array of a view is

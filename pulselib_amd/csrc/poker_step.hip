@@ -27,7 +27,7 @@ namespace {
 // dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
 // (hole cards [16][P_][2], ranks [16][P_], street equities [16][3][P_], deck window [16][8]);
 // 16-byte aligned so that the observation block of the next wavefront is.
-__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 6 + 8) + 3) & ~3; }
+__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 7 + 8) + 3) & ~3; }
 
 struct PolicyArgs {
     uint64_t types_packed, seed, step_counter, table_id0;
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     int32_t* const l_prerank = l_hands + TPW * P_ * 2;                   // [TPW][P_]
     float* const l_preeq = reinterpret_cast<float*>(l_prerank + TPW * P_);  // [TPW][3][P_]
     int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + TPW * 3 * P_);  // [TPW][8]: cards at deck position dpos0 + 0..7
+    int32_t* const l_class = l_deck + TPW * 8;                            // [TPW][P_]: hand class of every seat (scripted players)
     constexpr int DPL = 8 / LPT;                                         // deck-window entries each lane stages
     const int dpos0 = dpos;
     bool seat_hit[SPL];               // chunk: the cache entry of this lane's seat k was made from the hole cards it holds now
@@ -214,7 +215,14 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
         for (int k = 0; k < SPL; ++k) {
             const int seat = SEAT(k);
             *reinterpret_cast<int2*>(l_hands + (q * P_ + seat) * 2) = make_int2(h0[k], h1[k]);
-            seat_hit[k] = (uint32_t)ph_[k] == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);        // hole cards are fixed for the episode
+            seat_hit[k] = ((uint32_t)ph_[k] & (kPreHandsValid * 2u - 1u)) == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);   // hole cards are fixed for the episode
+            uint32_t cls = (uint32_t)ph_[k] >> kClsShift;                    // the reset kernel classified the cards the tag names
+            if (POLICY && !seat_hit[k]) {          // seats outside the hand hold (-1, -1): a constant; anything else (no cache, poked cards) is classified here
+                const bool empty = h0[k] == -1 && h1[k] == -1;
+                cls = hand_class(-1, -1);
+                if (!empty) cls = hand_class(h0[k], h1[k]);
+            }
+            l_class[q * P_ + seat] = (int32_t)cls;
             l_prerank[q * P_ + seat] = pr_[k];
             l_preeq[(q * 3 + 0) * P_ + seat] = __int_as_float(e1_[k]); l_preeq[(q * 3 + 1) * P_ + seat] = __int_as_float(e2_[k]);
             l_preeq[(q * 3 + 2) * P_ + seat] = __int_as_float(e3_[k]);
@@ -286,11 +294,12 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     // between the observation a step writes (for the NEXT seat to act) and the following step's capture, so a chunk
     // carries these five values from one step to the next instead of picking them twice.
     int a_status = 0, a_stack = 0, a_bet = 0, a_h0 = 0, a_h1 = 0;
+    uint32_t a_cls = 0;                  // chunk: the hand class of the seat to act instead of its two cards
+    auto class_of_seat = [&](int seat) -> uint32_t { return seat < P_ ? (uint32_t)l_class[q * P_ + seat] : hand_class(0, 0); };
     if (MULTI) {
         const int seat0 = idx & 15;
         a_status = SEAT_PICK(status, seat0); a_stack = SEAT_PICK(stack, seat0); a_bet = SEAT_PICK(bet, seat0);
-        const int2 h = hand_of_seat(seat0);
-        a_h0 = h.x; a_h1 = h.y;
+        a_cls = class_of_seat(seat0);
     }
     const int n_steps = MULTI ? ca.n_steps : 1;
     // output buffers of this step / of the next one: swapped at the end of every step (scalar moves; a select on the
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             }
             const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
             if (type != PULSE_AGENT_EXTERNAL) {
-                act64 = scripted_action(type, a_h0, a_h1, pot, draw);
+                act64 = MULTI ? scripted_action_cls(type, a_cls, pot, draw) : scripted_action(type, a_h0, a_h1, pot, draw);
                 if (j == 0) sto_in_loop(actions, ut * 8u, (int64_t)act64);
             }
         }
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                             } else {
                                 const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
                                 const float pe = ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
-                                hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
+                                hit = (ph & (kPreHandsValid * 2u - 1u)) == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
                                 e = pe;
                             }
                         }
@@ -469,7 +478,8 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
         }
         // a chunk fetches the next actor's hole cards now; they are first needed by the observation below
         int2 next_hand = make_int2(0, 0);
-        if (MULTI) next_hand = hand_of_seat(idx & 15);
+        uint32_t next_cls = 0;
+        if (MULTI) { next_hand = hand_of_seat(idx & 15); next_cls = class_of_seat(idx & 15); }
 
         STAMP(6);   // advance / deal done
         // ---- 4) payouts on newly finished tables (PokerGPU.py:619-623)
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                                 rank[k] = l_prerank[q * P_ + seat];
                             } else {
                                 const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
-                                hit = ph == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
+                                hit = (ph & (kPreHandsValid * 2u - 1u)) == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
                                 rank[k] = ldo(v.pre_rank, ROW_OFF(k));
                             }
                         }
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             const int seat_i = idx & 15;
             const int n_h0 = MULTI ? next_hand.x : SEAT_PICK(h0, seat_i), n_h1 = MULTI ? next_hand.y : SEAT_PICK(h1, seat_i);
             const int n_stack = SEAT_PICK(stack, seat_i), n_status = SEAT_PICK(status, seat_i), n_bet = SEAT_PICK(bet, seat_i);
-            if (MULTI) { a_status = n_status; a_stack = n_stack; a_bet = n_bet; a_h0 = n_h0; a_h1 = n_h1; }   // the next step's actor
+            if (MULTI) { a_status = n_status; a_stack = n_stack; a_bet = n_bet; a_cls = next_cls; }   // the next step's actor
             const int idxm = mod_near(idx, A);
             const int pos = mod_near(idx - button, A);
             // columns 0..12, LPT per pass: lane j writes column LPT*pass + j (an LPT-way select per pass)
@@ -638,7 +648,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             // (not reachable: a chunk always has PULSE_PH_OBS) keep the carried actor consistent anyway
             const int seat_i = idx & 15;
             a_status = SEAT_PICK(status, seat_i); a_stack = SEAT_PICK(stack, seat_i); a_bet = SEAT_PICK(bet, seat_i);
-            a_h0 = next_hand.x; a_h1 = next_hand.y;
+            a_cls = next_cls;
         }
         STAMP(9);   // observation stores issued
         if ((PH & PULSE_PH_ADVANCE) && j == 0) sto_in_loop(done_dst, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
