@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     // bet_dirty = {pot, highest, agg, acted, last_raise_size, idx}, street_dirty = {stage, deck position, dirty flag},
     // board_dirty = the five board cards.
     uint32_t cells_dirty = 0;
-    bool bet_dirty = false, street_dirty = false, board_dirty = false;
+    bool bet_dirty = false, street_dirty = false, board_dirty = false, eq_dirty = false, act_dirty = false;
     int prev_stack = 0, prev_invested = 0;
 
     // seat-set bitmask of a per-seat predicate / value of one seat, visible to every lane of the table
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             const int type = (int)((pa.types_packed >> (4 * (idx & 15))) & 15u);
             if (type != PULSE_AGENT_EXTERNAL) {
                 act64 = MULTI ? scripted_action_cls(type, a_cls, pot, draw) : scripted_action(type, a_h0, a_h1, pot, draw);
-                if (j == 0) sto_in_loop(actions, ut * 8u, (int64_t)act64);
+                act_dirty = true;                  // stored once, after the last step (a later step's action overwrites it anyway)
             }
         }
         const int action = act64 < -1 ? -1 : (act64 > 13 ? 13 : (int)act64);   // masks only test ==0, ==1, >=2, 2, 3..11, 12
@@ -385,9 +385,8 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                         }
                     }
                     eq[k] = e;
-                    if (seat < A) sto_in_loop(v.equities, (eq0 + (uint32_t)seat) * 4u, e);
                 }
-                dirty = false; street_dirty = true;
+                dirty = false; street_dirty = true; eq_dirty = true;
             }
         }
         float e_actor;
@@ -675,6 +674,11 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
             if (PH & PULSE_PH_EXECUTE) sto(vs.status, ROW_OFF(k), status[k]);
         }
     }
+    if ((PH & PULSE_PH_EQUITY) && eq_dirty) {          // the equities as the last step that recomputed them left them (PokerGPU.py:455-525)
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) if (SEAT(k) < A) sto(vs.equities, (eq0 + (uint32_t)SEAT(k)) * 4u, eq[k]);
+    }
+    if (POLICY && act_dirty && j == 0) sto(MULTI ? *reinterpret_cast<int64_t* const*>(kernarg + sizeof(PulsePokerView)) : actions, ut * 8u, (int64_t)act64);
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
         if (board_dirty) {
             static_assert(LPT == 4 || LPT == 2, "board store");
