@@ -110,9 +110,11 @@ def _log(msg):
 
 
 # ------------------------------------------------------------------------------------------------ episode loop
-# An event pair (two barrier packets on the launch stream, ~7 us of queue gap each) brackets 8 consecutive chunk launches
-# once every TIME_EVERY chunks: every episode bracketed (TIME_EVERY = 8) cost the loop 4 % of its throughput.
-TIME_EVERY = 32
+# The kernel timer (HIP events on the launch stream) brackets every chunk launch of every TIME_EVERY-th EPISODE, whole
+# episodes only: a launch costs 0.55x..1x of the mean depending on the phase of the episode it falls in, so brackets
+# that start at arbitrary chunks and end with the episode would over-sample its cheap tail.  (An event record is a
+# barrier packet, ~7 us of queue gap: with every episode bracketed the loop ran 4 % slower.)
+TIME_EVERY = 4
 
 
 class EpisodeLoop:
@@ -147,8 +149,9 @@ class EpisodeLoop:
         native_loop = hasattr(self.env, "rollout_until") and getattr(self.rule, "handle", None) is not None and self.rule.exchange != "host"
         while native_loop and done < k:
             # the chunks of the episode and the rule's verdicts run in one native call (no interpreter per chunk)
+            timed = timer is not None and time_every > 0 and self.episode % time_every == 0
             n, over = self.env.rollout_until(self.native, self.actions, CHECK_INTERVAL, min(k - done, self.max_episode_steps - self.steps_in_episode),
-                                             self.global_step, self.rule, timer=timer, time_every=time_every)
+                                             self.global_step, self.rule, timer=timer if timed else None, time_every=1 if timed else 0)
             self.calls += -(-n // CHECK_INTERVAL)
             self.global_step += n
             self.steps_in_episode += n
@@ -159,7 +162,7 @@ class EpisodeLoop:
                 self.new_episode()
         while done < k:
             n = min(CHECK_INTERVAL, k - done, self.max_episode_steps - self.steps_in_episode)
-            tm = timer if (timer is not None and time_every > 0 and self.calls % time_every == 0) else None
+            tm = timer if (timer is not None and time_every > 0 and self.episode % time_every == 0) else None
             self.env.rollout(self.native, self.actions, n, self.global_step, timer=tm, stop_rule=self.rule)
             self.calls += 1
             self.global_step += n
