@@ -14,6 +14,7 @@ Differences a caller can observe (all deliberate):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -259,6 +260,13 @@ class PokerGPU(_EnvBase):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _on_device(self):
+        """The C entry points launch on the CURRENT device: make that the device this environment's tensors live on
+        (a no-op context in the one-GPU-per-process layout the bench and the trainer use)."""
+        if torch.cuda.current_device() == self.device.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
+
     def _actions(self, actions):
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int64 and actions.device == self.device
                 and actions.is_contiguous()):
@@ -316,7 +324,8 @@ class PokerGPU(_EnvBase):
         o.prefixed_decks = deck_tensor.data_ptr() if deck_tensor is not None else None
         o.decks_out = self.decks.data_ptr()
         o.shuffle_key_bits = int(getattr(self, "_shuffle_key_bits", 0))      # test hook (pulse_env.h)
-        _native.check(self._lib.pulse_poker_reset(C.byref(v), C.byref(o), self._stream()), "pulse_poker_reset")
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_reset(C.byref(v), C.byref(o), self._stream()), "pulse_poker_reset")
         self.button_pos = self.button[0]
         self._has_episode = True
         self.episode += 1
@@ -332,8 +341,9 @@ class PokerGPU(_EnvBase):
                 self.calculate_equities()
         v = self._view()
         rewards = self._rewards[self._pp]
-        _native.check(self._lib.pulse_poker_step(C.byref(v), actions.data_ptr(), rewards.data_ptr(), self._stream()),
-                      "pulse_poker_step")
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_step(C.byref(v), actions.data_ptr(), rewards.data_ptr(), self._stream()),
+                          "pulse_poker_step")
         pp = 1 - self._pp
         object.__setattr__(self, "_pp", pp)
         object.__setattr__(self, "is_done", self._done_bufs[pp])
@@ -352,9 +362,10 @@ class PokerGPU(_EnvBase):
             types = self._types_cache[key] = (C.c_uint8 * self.n_players)(*key)
         v = self._view()
         rewards = self._rewards[self._pp]
-        _native.check(self._lib.pulse_poker_policy_step(C.byref(v), types, self.seed & (2**64 - 1), int(step_counter),
-                                                        self.table_id0, actions.data_ptr(), rewards.data_ptr(),
-                                                        self._stream()), "pulse_poker_policy_step")
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_policy_step(C.byref(v), types, self.seed & (2**64 - 1), int(step_counter),
+                                                            self.table_id0, actions.data_ptr(), rewards.data_ptr(),
+                                                            self._stream()), "pulse_poker_policy_step")
         pp = 1 - self._pp
         object.__setattr__(self, "_pp", pp)
         object.__setattr__(self, "is_done", self._done_bufs[pp])
@@ -378,13 +389,14 @@ class PokerGPU(_EnvBase):
         if self._view_dirty:
             self._build_views()
         pp = self._pp
-        _native.check(self._lib.pulse_poker_rollout(C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types,
-                                                    self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
-                                                    actions.data_ptr(), self._rewards[pp].data_ptr(),
-                                                    self._rewards[1 - pp].data_ptr(), int(n_steps),
-                                                    None if timer is None else timer.handle,
-                                                    None if stop_rule is None else stop_rule.handle,
-                                                    self._stream()), "pulse_poker_rollout")
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_rollout(C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types,
+                                                        self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
+                                                        actions.data_ptr(), self._rewards[pp].data_ptr(),
+                                                        self._rewards[1 - pp].data_ptr(), int(n_steps),
+                                                        None if timer is None else timer.handle,
+                                                        None if stop_rule is None else stop_rule.handle,
+                                                        self._stream()), "pulse_poker_rollout")
         if n_steps <= 0:
             return self.obs, self._rewards[pp], self.is_done, self.is_truncated, self.get_info()
         last = pp if (n_steps - 1) % 2 == 0 else 1 - pp
@@ -413,11 +425,12 @@ class PokerGPU(_EnvBase):
             self._build_views()
         pp = self._pp
         done, over = C.c_int32(0), C.c_int32(0)
-        _native.check(self._lib.pulse_poker_rollout_until(
-            C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types, self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
-            actions.data_ptr(), self._rewards[pp].data_ptr(), self._rewards[1 - pp].data_ptr(), int(chunk_steps), int(max_steps),
-            None if timer is None else timer.handle, int(time_every), stop_rule.handle, self._stream(), C.byref(done), C.byref(over)),
-            "pulse_poker_rollout_until")
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_rollout_until(
+                C.byref(self._views[pp]), C.byref(self._views[1 - pp]), types, self.seed & (2**64 - 1), int(step_counter0), self.table_id0,
+                actions.data_ptr(), self._rewards[pp].data_ptr(), self._rewards[1 - pp].data_ptr(), int(chunk_steps), int(max_steps),
+                None if timer is None else timer.handle, int(time_every), stop_rule.handle, self._stream(), C.byref(done), C.byref(over)),
+                "pulse_poker_rollout_until")
         stop_rule.decisions += -(-done.value // max(int(chunk_steps), 1))
         if done.value % 2:
             new_pp = 1 - pp
@@ -435,10 +448,11 @@ class PokerGPU(_EnvBase):
         idx_t = None
         if actor_idx is not None:
             idx_t = torch.as_tensor(actor_idx).to(device=self.device, dtype=torch.int32).contiguous()
-        _native.check(self._lib.pulse_poker_phases(C.byref(v), phases, act_t.data_ptr() if act_t is not None else None,
-                                                   idx_t.data_ptr() if idx_t is not None else None,
-                                                   rewards.data_ptr() if rewards is not None else None, self._stream()),
-                      "pulse_poker_phases")
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_phases(C.byref(v), phases, act_t.data_ptr() if act_t is not None else None,
+                                                       idx_t.data_ptr() if idx_t is not None else None,
+                                                       rewards.data_ptr() if rewards is not None else None, self._stream()),
+                          "pulse_poker_phases")
         del act_t, idx_t
 
     def get_obs(self):                               # PokerGPU.py:159-179

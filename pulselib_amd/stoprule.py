@@ -135,8 +135,8 @@ class LaggedDoneCount:
             raise ValueError(f"exchange must be 'local', 'host', 'shm' or 'rccl', got {exchange!r}")
         if backend is not None and exchange == "rccl":
             raise ValueError("a host-side count backend cannot use the RCCL exchange")
-        if exchange != "local" and world == 1:
-            exchange = "local"
+        if exchange != "local" and world == 1 and not (exchange == "rccl" and comm is not None):
+            exchange = "local"        # (an explicit communicator of one rank is honoured: the single-GPU test of the RCCL path)
         self.exchange = exchange
         self.n_global = int(n_global) if n_global is not None else (self.n if exchange == "local" else None)
         if self.n_global is None:

@@ -739,6 +739,49 @@ def test_native_episode_loop_equals_rollout_plus_verdict_per_chunk(lag):
     ra.close(); rb.close()
 
 
+def test_rccl_exchange_with_one_rank_decides_like_the_local_rule():
+    """exchange="rccl": the stop rule's count goes through a NATIVE RCCL communicator (librccl bound with dlopen,
+    csrc/stoprule.hip) -- one int64 all-reduce per check point on the rule's side stream, handed over by events.  One
+    rank is all a single-GPU box can run (RCCL refuses two ranks on one device); it still exercises the binding, the
+    communicator, the stream hand-over, the native decision and pulse_comm_all_reduce_i64 itself.  The episodes must
+    come out exactly as with the local rule."""
+    import torch.distributed as dist
+    from pulselib_amd.stoprule import LaggedDoneCount, NativeComm
+    dev = torch.device(DEV)
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1)
+    try:
+        comm = NativeComm(dev)
+        t = torch.tensor([5, -7, 1 << 40], dtype=torch.int64, device=dev)
+        assert comm.all_reduce_i64_(t).cpu().tolist() == [5, -7, 1 << 40]
+        N = 4096
+        kw = dict(n_players=6, max_players=10, n_games=N, seed=33, table_id0=9)
+        a, b = _gpu_env(**kw), _gpu_env(**kw)
+        ra = LaggedDoneCount(dev, N, 0.8, lag=1, n_global=N, exchange="rccl", comm=comm)
+        rb = LaggedDoneCount(dev, N, 0.8, lag=1)
+        assert ra.exchange == "rccl" and rb.exchange == "local"
+        types = [1, 3, 2, 4, 5, 1]
+        acts = [torch.zeros(N, dtype=torch.long, device=dev) for _ in range(2)]
+        gstep, fired = 0, False
+        for e in range(4):
+            for env, rule in ((a, ra), (b, rb)):
+                env.reset(options={"active_players": 6 - e % 2, "rotation": e})
+                rule.drain()
+            got = a.rollout_until(types, acts[0], 5, 60, gstep, ra)
+            want = b.rollout_until(types, acts[1], 5, 60, gstep, rb)
+            assert got == want, f"episode {e}: rccl {got}, local {want}"
+            fired = fired or got[1]
+            gstep += got[0]
+            for name in ("stacks", "status", "pots", "stages", "idx", "is_done"):
+                np.testing.assert_array_equal(to_np(getattr(a, name)), to_np(getattr(b, name)), err_msg=f"episode {e} {name}")
+        assert fired
+        ra.close(); rb.close(); comm.close()
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 ROLLOUT_MEMORY = INT_KEYS + ("decks", "equities", "prev_stacks", "prev_invested", "equity_dirty")
 
 
