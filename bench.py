@@ -323,9 +323,14 @@ def main_rank(args):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # PULSE_BENCH_FORCE_DIST=1: initialise the process group for a world of one as well (what a one-GPU box can rehearse
+    # of the RCCL leg: backend init, barrier, the MAX all-reduce)
+    if world > 1 or os.environ.get("PULSE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if one_device:
             dist.init_process_group(backend="gloo")
         else:
@@ -490,7 +495,10 @@ def launcher(args, argv):
         port = _free_port()
         procs, errs = [], []
         for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+            # a clean rendezvous of our own: nothing of an enclosing torchrun worker's (TORCHELASTIC_USE_AGENT_STORE would
+            # make rank 0 look for the agent's store on OUR port and wait for ever)
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC")) and k not in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")}
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), PULSE_BENCH_WATCHDOG_S=str(max(30, limit - 30)))
             err = open(f"/tmp/pulse_bench_{os.getpid()}_a{attempt}_r{r}.err", "w+")
             errs.append(err)
@@ -542,7 +550,8 @@ if __name__ == "__main__":
     _args = parse_args()
     if _args.role == "cpu":
         print(json.dumps(cpu_baseline(_args)), flush=True)
-    elif _args.role == "rank" or _args.inproc or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PULSE_BENCH_INPROC") == "1":
+    elif (_args.role == "rank" or _args.inproc or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PULSE_BENCH_INPROC") == "1"
+          or "TORCHELASTIC_RUN_ID" in os.environ):          # a torchrun worker IS a rank, also in a world of one
         main_rank(_args)
     else:
         sys.exit(launcher(_args, sys.argv[1:]))
