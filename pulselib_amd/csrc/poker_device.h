@@ -145,6 +145,13 @@ template <class T> __device__ __forceinline__ void sto(T* __restrict__ base, uin
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = val;
 }
 
+// Store through a pointer that is known to be global memory (a pointer re-read from the kernel-argument segment is
+// generic to the compiler: it would emit flat_store, which also counts against lgkmcnt and is waited for by LDS reads).
+template <class T> __device__ __forceinline__ void stg(T* base, uint32_t byte_off, T val) {
+    typedef __attribute__((address_space(1))) T GlobalT;
+    *(GlobalT*)((__attribute__((address_space(1))) char*)base + byte_off) = val;
+}
+
 // The same store from inside a long loop: the byte offset passes through an empty asm, so the address cannot be
 // hoisted out of the loop as a 64-bit per-lane pointer (two VGPRs alive across the whole loop per store site, which
 // the register allocator then spills -- and a spill reload is a vector-memory load that waits behind every store in

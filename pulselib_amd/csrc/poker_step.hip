@@ -661,48 +661,52 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
     // ---- store: the groups whose flag was raised (one test per seat / per group instead of one branch per word).
     // In a chunk the ~25 state pointers would have to stay in scalar registers across the whole step loop (they were
     // spilled, 95 of them); the kernel argument block is re-read here through a pointer the compiler cannot see through.
-    const char* kernarg = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-    if (MULTI) asm volatile("" : "+s"(kernarg));
-    const PulsePokerView& vs = MULTI ? *reinterpret_cast<const PulsePokerView*>(kernarg) : v;   // the view is the first kernel argument
+    // The pointer stays in the constant address space (scalar loads of the array pointers, lgkmcnt only -- as a generic
+    // pointer they became vector loads waited for with vmcnt(0), i.e. behind every store in flight), and the stores go
+    // out as global stores (stg).
+    typedef const __attribute__((address_space(4))) PulsePokerView* ViewInKernarg;
+    ViewInKernarg vk = (ViewInKernarg)__builtin_amdgcn_kernarg_segment_ptr();       // the view is the first kernel argument
+    if (MULTI) asm volatile("" : "+s"(vk));
+#define VS(field) (MULTI ? vk->field : v.field)
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int seat = SEAT(k);
         if (seat < P && ((cells_dirty >> k) & 1u)) {
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(vs.stacks, ROW_OFF(k), stack[k]);
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(vs.current_round_bet, ROW_OFF(k), bet[k]);
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) sto(vs.total_invested, ROW_OFF(k), inv[k]);
-            if (PH & PULSE_PH_EXECUTE) sto(vs.status, ROW_OFF(k), status[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) stg(VS(stacks), ROW_OFF(k), stack[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) stg(VS(current_round_bet), ROW_OFF(k), bet[k]);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_CLEARDONE)) stg(VS(total_invested), ROW_OFF(k), inv[k]);
+            if (PH & PULSE_PH_EXECUTE) stg(VS(status), ROW_OFF(k), status[k]);
         }
     }
     if ((PH & PULSE_PH_EQUITY) && eq_dirty) {          // the equities as the last step that recomputed them left them (PokerGPU.py:455-525)
 #pragma unroll
-        for (int k = 0; k < SPL; ++k) if (SEAT(k) < A) sto(vs.equities, (eq0 + (uint32_t)SEAT(k)) * 4u, eq[k]);
+        for (int k = 0; k < SPL; ++k) if (SEAT(k) < A) stg(VS(equities), (eq0 + (uint32_t)SEAT(k)) * 4u, eq[k]);
     }
-    if (POLICY && act_dirty && j == 0) sto(MULTI ? *reinterpret_cast<int64_t* const*>(kernarg + sizeof(PulsePokerView)) : actions, ut * 8u, (int64_t)act64);
+    if (POLICY && act_dirty && j == 0) stg(MULTI ? *(int64_t* const __attribute__((address_space(4)))*)((const __attribute__((address_space(4))) char*)vk + sizeof(PulsePokerView)) : actions, ut * 8u, (int64_t)act64);
     if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) {
         if (board_dirty) {
             static_assert(LPT == 4 || LPT == 2, "board store");
             if (LPT == 4) {
-                sto(vs.board, bo + (uint32_t)j * 4u, j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3);
-                if (j == 0) sto(vs.board, bo + 16u, b4);
+                stg(VS(board), bo + (uint32_t)j * 4u, j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3);
+                if (j == 0) stg(VS(board), bo + 16u, b4);
             } else {
-                sto(vs.board, bo + (uint32_t)j * 4u, j == 0 ? b0 : b1);
-                sto(vs.board, bo + 8u + (uint32_t)j * 4u, j == 0 ? b2 : b3);
-                if (j == 0) sto(vs.board, bo + 16u, b4);
+                stg(VS(board), bo + (uint32_t)j * 4u, j == 0 ? b0 : b1);
+                stg(VS(board), bo + 8u + (uint32_t)j * 4u, j == 0 ? b2 : b3);
+                if (j == 0) stg(VS(board), bo + 16u, b4);
             }
         }
     }
     if (j == 0) {
-        if (PH & PULSE_PH_CAPTURE) { sto(vs.prev_stacks, so, prev_stack); sto(vs.prev_invested, so, prev_invested); }
+        if (PH & PULSE_PH_CAPTURE) { stg(VS(prev_stacks), so, prev_stack); stg(VS(prev_invested), so, prev_invested); }
         if (bet_dirty) {
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) sto(vs.pots, so, pot);
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) sto(vs.highest, so, highest);
-            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { sto(vs.agg, so, agg); sto(vs.acted, so, acted); sto(vs.last_raise_size, so, lrs); }
-            if (PH & PULSE_PH_ADVANCE) sto(vs.idx, so, idx);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_FOLDWIN | PULSE_PH_SHOWDOWN)) stg(VS(pots), so, pot);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE | PULSE_PH_CLEARDONE)) stg(VS(highest), so, highest);
+            if (PH & (PULSE_PH_EXECUTE | PULSE_PH_ADVANCE)) { stg(VS(agg), so, agg); stg(VS(acted), so, acted); stg(VS(last_raise_size), so, lrs); }
+            if (PH & PULSE_PH_ADVANCE) stg(VS(idx), so, idx);
         }
         if (street_dirty) {
-            if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { sto(vs.stages, so, stage); sto(vs.deck_positions, so, dpos); }
-            if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) sto(vs.equity_dirty, ut, (uint8_t)(dirty ? 1 : 0));
+            if (PH & (PULSE_PH_ADVANCE | PULSE_PH_SHOWDOWN)) { stg(VS(stages), so, stage); stg(VS(deck_positions), so, dpos); }
+            if (PH & (PULSE_PH_EQUITY | PULSE_PH_ADVANCE)) stg(VS(equity_dirty), ut, (uint8_t)(dirty ? 1 : 0));
         }
     }
     if (POLICY && pa.wave_done) {
@@ -721,6 +725,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
 #undef SEAT_PICK
 #undef ROW_OFF
 #undef SEAT
+#undef VS
 }
 
 // ---------------------------------------------------------------- host side
