@@ -301,6 +301,9 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
         a_status = SEAT_PICK(status, seat0); a_stack = SEAT_PICK(stack, seat0); a_bet = SEAT_PICK(bet, seat0);
         a_cls = class_of_seat(seat0);
     }
+    // the caller's action word was loaded with the state; pin its arrival to the prologue's waits: left pending, its one
+    // use after the loop (the final store of the action) became an s_waitcnt vmcnt(0) behind every store of the last step
+    if (MULTI) asm volatile("" : "+v"(act64));
     const int n_steps = MULTI ? ca.n_steps : 1;
     // output buffers of this step / of the next one: swapped at the end of every step (scalar moves; a select on the
     // step's parity made the compiler keep both sets of per-lane addresses alive across the loop -- and spill them)
