@@ -3,6 +3,7 @@ traffic of the chunk kernel with the calibration that corrects it, the SQ counte
 import collections
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
@@ -15,7 +16,7 @@ STEP = "poker_step_kernel"
 
 
 def counters(d, kname):
-    f = glob.glob(str(src / d / "*" / "*counter_collection.csv"))
+    f = sorted(glob.glob(str(src / d / "*" / "*counter_collection.csv")), key=os.path.getmtime, reverse=True)   # newest run first
     if not f:
         return {}
     acc = collections.defaultdict(list)
@@ -40,7 +41,7 @@ if cal_r and cal_w:
                    "how": "tools/pmc_calibrate.py: 512 MiB read / written with one dword per lane (the access shape of most of the kernel's loads and stores)"}
 
 for n in (65536, 1048576):
-    stats = glob.glob(str(src / f"trace_{n}" / "*" / "*kernel_stats.csv"))
+    stats = sorted(glob.glob(str(src / f"trace_{n}" / "*" / "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     if not stats:
         continue
     shutil.copy(stats[0], dst / f"bench_kernel_stats_{n}.csv")
@@ -73,7 +74,7 @@ for name in ("bench_default", "bench_driver_style"):
     f = src / f"{name}.log"
     if f.exists():
         shutil.copy(f, dst / f"{name}.json")
-tr = glob.glob(str(src / "trainer" / "*" / "*kernel_stats.csv"))
+tr = sorted(glob.glob(str(src / "trainer" / "*" / "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if tr:
     shutil.copy(tr[0], dst / "trainer_kernel_stats.csv")
     line = last_json(src / "trainer_plain.log")
