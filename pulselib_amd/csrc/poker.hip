@@ -219,7 +219,20 @@ __global__ __launch_bounds__(kBlock) void poker_stats_kernel(const uint8_t* __re
                                                             const uint8_t* __restrict__ mask, int n,
                                                             unsigned long long* stats, double* fstats) {
     int cnt = 0; double sum = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int stride = gridDim.x * kBlock;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {          // four elements per pass: their loads are in flight together
+        uint8_t d[4] = {0, 0, 0, 0}, mk[4] = {1, 1, 1, 1}; float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (is_done) d[u] = is_done[i + u * stride];
+            if (rewards) r[u] = rewards[i + u * stride];
+            if (rewards && mask) mk[u] = mask[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cnt += d[u] != 0; if (rewards && mk[u]) sum += (double)r[u]; }
+    }
+    for (; i < n; i += stride) {
         cnt += is_done ? (is_done[i] != 0) : 0;
         if (rewards && (!mask || mask[i])) sum += (double)rewards[i];
     }
@@ -372,7 +385,9 @@ int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_
                       double* fstats, void* stream) {
     if ((!stats && !fstats) || (rewards && !fstats) || n < 0) return pulse::fail(PULSE_EINVAL, "pulse_poker_stats: bad argument");
     if (n == 0) return 0;
-    const int grid = min(1024, (n + kBlock - 1) / kBlock);
+    // few, fat workgroups: every workgroup ends in atomics onto the same two or three words, and atomics from all XCDs
+    // onto one address cost more than the reads (8 us per 65,536 tables with one workgroup per 256 tables)
+    const int grid = max(1, min(256, n / (4 * kBlock)));
     hipLaunchKernelGGL(poker_stats_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, is_done, rewards, mask, n,
                        reinterpret_cast<unsigned long long*>(stats), fstats);
     return pulse::finish_launch("pulse_poker_stats");

@@ -233,7 +233,15 @@ __device__ __forceinline__ int first_after_near(uint32_t bits, int x, int A) {
 // nullptr: the device pair only.
 __device__ __forceinline__ void sum_and_publish(const uint32_t* __restrict__ partials, int n, long long* __restrict__ pair, long long* host, long long seq) {
     long long s = 0;
-    for (int i = threadIdx.x; i < n; i += kBlock) s += partials[i];
+    int i = threadIdx.x;
+    for (; i + 7 * kBlock < n; i += 8 * kBlock) {        // eight independent loads in flight (1 M tables: 65,536 words)
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = partials[i + u * kBlock];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    for (; i < n; i += kBlock) s += partials[i];
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     __shared__ long long w_[kBlock / 64];
     if ((threadIdx.x & 63) == 0) w_[threadIdx.x >> 6] = s;
