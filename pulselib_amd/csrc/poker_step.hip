@@ -3,13 +3,14 @@
 //
 // Replaces the ~1,700 eager torch dispatches of one PokerGPU.step (environments/Poker/PokerGPU.py:527-633).
 //
-// Mapping: a table is owned by LPT adjacent lanes (4 = one DPP quad, or 2), lane j owns seats j, j+LPT, j+2*LPT, ...
-// (SPL of them): 64/LPT tables per 64-wide wavefront.  Per-table scalars are replicated in the table's lanes, so the
-// scalar part of the state machine costs 1/LPT wave-instruction per table; per-seat rows ([N,P] int32, the reference's
-// own layout) are SPL unrolled dwords per lane.  Seat sets (ACTIVE seats, contenders, winners) are bitmasks OR-reduced
-// across the table's lanes with DPP quad_perm modifiers (no LDS); "first ACTIVE seat after x" is a rotate + ffs on the
-// mask; side-pot layers are min/max butterflies.  LPT = 4 is what is built (see lanes_for below for the measurement).  All integer arithmetic is the reference's; the fp32 reward keeps
-// torch's op order (no contraction; tanh rounded once from double).
+// Mapping: a table is owned by LPT adjacent lanes (4 = one DPP quad; the code also compiles for 2), lane j owns the SPL
+// consecutive seats SPL*j .. SPL*j+SPL-1: 64/LPT tables per 64-wide wavefront.  Per-table scalars are replicated in the
+// table's lanes, so the scalar part of the state machine costs 1/LPT wave-instruction per table; a lane's cells of a
+// per-seat row ([N,P] int32, the reference's own layout) are one 12- or 16-byte load.  Seat sets (ACTIVE seats,
+// contenders, winners) are bitmasks OR-reduced across the table's lanes with DPP quad_perm modifiers (no LDS); "first
+// ACTIVE seat after x" is a rotate + ffs on the mask; side-pot layers are min/max butterflies.  LPT = 4 is what is built
+// (see lanes_for below for the measurement).  All integer arithmetic is the reference's; the fp32 reward keeps torch's
+// op order (no contraction; tanh rounded once from double).
 //
 // Memory: single step -- state is read once and only the words that changed are written back, in the reference's
 // own SoA tensors, so the drop-in class exposes them unchanged.  Chunk (pulse_poker_rollout) -- state is read once
@@ -25,7 +26,7 @@ using namespace pulse_dev;
 namespace {
 
 // dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
-// (hole cards [16][P_][2], ranks [16][P_], street equities [16][3][P_], deck window [16][8]);
+// (hole cards [16][P_][2], ranks [16][P_], street equities [16][3][P_], deck window [16][8], hand classes [16][P_]);
 // 16-byte aligned so that the observation block of the next wavefront is.
 __host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 7 + 8) + 3) & ~3; }
 
