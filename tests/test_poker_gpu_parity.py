@@ -398,6 +398,65 @@ def test_sharding_is_invisible_to_the_games():
             np.testing.assert_array_equal(got, to_np(getattr(whole, name)), err_msg=name)
 
 
+def test_config4_full_size_one_run_equals_its_eight_shards_and_never_mints_chips():
+    """BASELINE.json config 4 at its FULL size on one GPU: 1,048,576 tables in one environment against the same tables
+    as the eight 131,072-table shards of an 8-GPU job (table_id0 = rank * 131,072), through two episodes of 5-step
+    chunk launches with the scripted opponents.  Size-independent properties checked on the full run: every deck is a
+    permutation of 1..52 (sum and sum of squares), no table ever gains chips (stacks + pot never grows; it shrinks only
+    where the reference's side-pot rule drops a layer), done flags never clear inside an episode; and the checksum of checksums: every state array of every shard
+    equals its slice of the full run, bit for bit."""
+    from pulselib_amd.sharding import shard_tables
+    total, world, P = 1048576, 8, 10
+    kw = dict(n_players=P, max_players=P, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=20260401)
+    whole = _gpu_env(n_games=total, table_id0=0, **kw)
+    types = [1, 3, 2, 2, 4, 3, 1, 4, 5, 3]
+    acts = torch.zeros(total, dtype=torch.long, device=DEV)
+    names = INT_KEYS + ("equities", "prev_stacks", "prev_invested")
+    chunks = (5, 5, 5, 3)
+    decks = []                                                       # per episode (a deck does not change inside one)
+    snaps = []                                                       # the full run's state after every chunk, on the host
+    gstep = 0
+    for e, A in enumerate((9, 6)):
+        whole.reset(options={"active_players": A, "rotation": e})
+        d64 = whole.decks.to(torch.int64)
+        assert bool((d64.sum(dim=1) == 1378).all()) and bool(((d64 * d64).sum(dim=1) == 48230).all()), "decks are not permutations of 1..52"
+        decks.append(to_np(whole.decks))
+        chips = whole.stacks.to(torch.int64).sum(dim=1) + whole.pots.to(torch.int64)
+        done_before = whole.is_done.clone()
+        for n in chunks:
+            whole.rollout(types, acts, n, gstep)
+            gstep += n
+            now = whole.stacks.to(torch.int64).sum(dim=1) + whole.pots.to(torch.int64)
+            # the reference's side-pot rule does not award a layer no eligible seat reaches (PokerGPU.py:340-378; the
+            # "dropped layer" known answers of tests/scenarios.py): chips may vanish on a handful of tables, never appear
+            assert bool((now <= chips).all()), f"episode {e}: chips appeared on {int((now > chips).sum())} tables"
+            assert int((now < chips).sum()) < total // 1000, f"episode {e}: chips vanished on {int((now < chips).sum())} tables"
+            chips = now
+            assert bool((whole.is_done | ~done_before).all()), f"episode {e}: a done flag cleared"
+            done_before = whole.is_done.clone()
+            snaps.append({k: to_np(getattr(whole, k)) for k in names + ("obs",)} | {"actions": to_np(acts)})
+        assert 0.2 < float(whole.is_done.float().mean()) <= 1.0
+    del whole
+    torch.cuda.empty_cache()
+    for rank in range(world):
+        n_local, t0 = shard_tables(total, world, rank)
+        part = _gpu_env(n_games=n_local, table_id0=t0, **kw)
+        a = torch.zeros(n_local, dtype=torch.long, device=DEV)
+        gstep, c = 0, 0
+        for e, A in enumerate((9, 6)):
+            part.reset(options={"active_players": A, "rotation": e})
+            np.testing.assert_array_equal(to_np(part.decks), decks[e][t0:t0 + n_local], err_msg=f"rank {rank} episode {e} decks")
+            for n in chunks:
+                part.rollout(types, a, n, gstep)
+                gstep += n
+                want = snaps[c]
+                c += 1
+                for k in names + ("obs",):
+                    np.testing.assert_array_equal(to_np(getattr(part, k)), want[k][t0:t0 + n_local], err_msg=f"rank {rank} episode {e} chunk {c} {k}")
+                np.testing.assert_array_equal(to_np(a), want["actions"][t0:t0 + n_local], err_msg=f"rank {rank} actions")
+        del part
+
+
 # ---- white-box helper contracts (data restated from the reference's tests/poker/test_poker_gpu_state_contracts.py
 #      :69-127 and test_poker_gpu_reward_equity_contracts.py:26-110) ------------------------------------------
 def _fresh(n_players, n_games=1):
