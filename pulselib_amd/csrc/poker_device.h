@@ -231,24 +231,25 @@ __device__ __forceinline__ int first_after_near(uint32_t bits, int x, int A) {
 // Sum a check point's partial done-counts (one workgroup) and publish {local, global = local, sequence number} into
 // coherent pinned host memory, the sequence number last behind a system-scope fence: the host polls it.  `host` =
 // nullptr: the device pair only.
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void sum_and_publish(const uint32_t* __restrict__ partials, int n, long long* __restrict__ pair, long long* host, long long seq) {
     long long s = 0;
     int i = threadIdx.x;
-    for (; i + 7 * kBlock < n; i += 8 * kBlock) {        // eight independent loads in flight (1 M tables: 65,536 words)
+    for (; i + 7 * BLOCK < n; i += 8 * BLOCK) {        // eight independent loads in flight (1 M tables: 65,536 words)
         uint32_t x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = partials[i + u * kBlock];
+        for (int u = 0; u < 8; ++u) x[u] = partials[i + u * BLOCK];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += x[u];
     }
-    for (; i < n; i += kBlock) s += partials[i];
+    for (; i < n; i += BLOCK) s += partials[i];
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    __shared__ long long w_[kBlock / 64];
+    __shared__ long long w_[BLOCK / 64];
     if ((threadIdx.x & 63) == 0) w_[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         long long t = 0;
-        for (int k = 0; k < kBlock / 64; ++k) t += w_[k];
+        for (int k = 0; k < BLOCK / 64; ++k) t += w_[k];
         if (pair) { pair[0] = t; pair[1] = t; }
         if (host) {
             host[0] = t; host[1] = t;

@@ -25,6 +25,14 @@ using namespace pulse_dev;
 
 namespace {
 
+// threads per workgroup of the step kernel.  Its wavefronts do not cooperate (only the stop rule's sum in workgroup 0
+// does), so smaller workgroups only change how finely the dispatcher refills a CU: measured per 5-step chunk at 65,536 /
+// 1,048,576 tables, 256 threads: 39.5 / 421 us, 128: 39.6 / 404, 64: 40.5 / 400.
+#ifndef PULSE_STEP_BLOCK
+#define PULSE_STEP_BLOCK 128
+#endif
+constexpr int kStepBlock = PULSE_STEP_BLOCK;
+
 // dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
 // (hole cards [16][P_][2], ranks [16][P_], street equities [16][3][P_], deck window [16][8], hand classes [16][P_]);
 // 16-byte aligned so that the observation block of the next wavefront is.
@@ -50,7 +58,7 @@ struct ChunkArgs {                         // MULTI only: the odd steps' output 
 #if PULSE_STAMPS
 __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i) do { if ((threadIdx.x & 63) == 0 && g_stamp_buf) { __builtin_amdgcn_sched_barrier(0); \
-    g_stamp_buf[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    g_stamp_buf[((size_t)blockIdx.x * (kStepBlock / 64) + (threadIdx.x >> 6)) * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -102,7 +110,7 @@ template <int N_> struct alignas(4) SeatCells { int32_t v[N_]; };
 // MULTI: ca.n_steps steps in one launch (fused policy only); step i writes observation / done flag / reward into
 // the even (i even) or odd buffers, as n single launches on the two ping-pong views would.
 template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, bool MULTI>
-__global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
+__global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
                                                            const int32_t* __restrict__ actor_idx_in,
                                                            float* __restrict__ rewards, const PolicyArgs pa, const ChunkArgs ca) {
     static_assert((LPT == 4 && (SPL == 3 || SPL == 4)) || (LPT == 2 && (SPL == 5 || SPL == 8)), "lanes per table x seats per lane: 4x3, 4x4, 2x5, 2x8");
@@ -114,9 +122,9 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
         // the host BEFORE its own tables.  (A separate last workgroup did this in the first version; at 65,536 tables
         // the grid fills the chip exactly, so that workgroup only got a slot when the first one retired and the host
         // learned the count ~35 us later than it could -- too late to keep the queue fed at an episode boundary.)
-        sum_and_publish(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
+        sum_and_publish<kStepBlock>(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
     }
-    const int gt = blockIdx.x * kBlock + threadIdx.x;
+    const int gt = blockIdx.x * kStepBlock + threadIdx.x;
     const int t = gt / LPT;
     const int j_lane = gt % LPT;
     const int j = j_lane;
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int n4 = TPW / 4 * v.obs_size;                             // int4 per wavefront block
-                const int tw0 = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
+                const int tw0 = (int)((blockIdx.x * kStepBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
                 const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
                 const int4* src = reinterpret_cast<const int4*>(l_obs);
                 for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
         // tables are done -- a plain store, summed on a side stream (atomics onto shared counters cost this launch
         // as much as the separate counting kernel they would replace)
         const int c = __popcll(__ballot(done && j == 0));
-        if ((threadIdx.x & 63) == 0) pa.wave_done[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = (uint32_t)c;
+        if ((threadIdx.x & 63) == 0) pa.wave_done[blockIdx.x * (kStepBlock / 64) + (threadIdx.x >> 6)] = (uint32_t)c;
     }
     STAMP(10);  // state stores issued
 #if PULSE_STAMPS
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(kBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(co
 // dependent chain whose length does not shrink with fewer lanes per table, and with half the wavefronts there is
 // less to overlap it with: 46.9 vs 43.6 us and 553 vs 463 us per 5-step chunk.  Not instantiated.)
 inline int lanes_for(const PulsePokerView&, bool) { return 4; }
-inline dim3 step_grid(const PulsePokerView& v, int lpt) { return dim3((unsigned)(((long long)v.n_games * lpt + kBlock - 1) / kBlock)); }
+inline dim3 step_grid(const PulsePokerView& v, int lpt) { return dim3((unsigned)(((long long)v.n_games * lpt + kStepBlock - 1) / kStepBlock)); }
 inline bool obs_staging(const PulsePokerView& v, const float* obs_odd, int lpt) {
     return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games % (64 / lpt)) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
 }
@@ -747,11 +755,11 @@ template <uint32_t PH, bool POLICY, int LPT, int SPL, bool MULTI>
 void launch_one(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, const ChunkArgs& ca,
                 hipStream_t st) {
     dim3 grid = step_grid(v, LPT);
-    const dim3 block(kBlock);
+    const dim3 block(kStepBlock);
     constexpr int TPW = 64 / LPT;
     const bool wobs = (PH & PULSE_PH_OBS) && (MULTI || PH == PULSE_PH_STEP) && obs_staging(v, MULTI ? ca.obs_odd : nullptr, LPT);
-    const size_t lds = MULTI ? sizeof(int32_t) * (size_t)(kBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, LPT * SPL, TPW)
-                             : (wobs ? sizeof(float) * (size_t)(kBlock / 64) * TPW * (size_t)v.obs_size : 0);
+    const size_t lds = MULTI ? sizeof(int32_t) * (size_t)(kStepBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, LPT * SPL, TPW)
+                             : (wobs ? sizeof(float) * (size_t)(kStepBlock / 64) * TPW * (size_t)v.obs_size : 0);
     constexpr bool W = PH == PULSE_PH_STEP;          // only the full step is instantiated with observation staging
     if (lds > 48 * 1024) {                           // beyond the default dynamic-LDS limit: raise it (to what this launch needs)
         static size_t raised[2] = {0, 0};
@@ -874,7 +882,7 @@ int pulse_poker_ablate(const PulsePokerView* v, uint32_t phases, int64_t* action
                        uint64_t step_counter, void* stream) {
     if (int rc = pulse::check_view(v, "pulse_poker_ablate")) return rc;
     if (v->max_players > 12) return pulse::fail(PULSE_EINVAL, "pulse_poker_ablate: max_players <= 12");
-    const dim3 grid = step_grid(*v, 4), block(kBlock);
+    const dim3 grid = step_grid(*v, 4), block(kStepBlock);
     const PolicyArgs pa{types_packed, 1, step_counter, 0, nullptr, nullptr, 0, nullptr, 0};
     const ChunkArgs ca{nullptr, nullptr, 1};
     hipStream_t st = (hipStream_t)stream;
