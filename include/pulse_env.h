@@ -62,6 +62,7 @@ enum {
 /* flags: kernel variants a caller (or a test) selects per view; 0 = the product defaults */
 #define PULSE_VIEW_NO_OBS_STAGING 0x1  /* store the observation column by column instead of LDS-staged 16-byte bursts  */
 #define PULSE_VIEW_NO_CHUNK       0x2  /* pulse_poker_rollout: one launch per step instead of one launch per chunk     */
+#define PULSE_VIEW_FOUR_LANES     0x4  /* chunk launches: four lanes per table also where two are the default (<= 10 seats) */
 typedef struct PulsePokerView {
     int32_t n_games, n_players, active_players, max_players;   /* n_games <= 2^24 per view (shard larger batches) */
     int32_t obs_size, hand_ranks_len;

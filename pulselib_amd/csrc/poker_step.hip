@@ -8,8 +8,8 @@
 // table's lanes, so the scalar part of the state machine costs 1/LPT wave-instruction per table; a lane's cells of a
 // per-seat row ([N,P] int32, the reference's own layout) are one 12- or 16-byte load.  Seat sets (ACTIVE seats,
 // contenders, winners) are bitmasks OR-reduced across the table's lanes with DPP quad_perm modifiers (no LDS); "first
-// ACTIVE seat after x" is a rotate + ffs on the mask; side-pot layers are min/max butterflies.  LPT = 4 is what is built
-// (see lanes_for below for the measurement).  All integer arithmetic is the reference's; the fp32 reward keeps torch's
+// ACTIVE seat after x" is a rotate + ffs on the mask; side-pot layers are min/max butterflies.  Single steps run with
+// LPT = 4, chunks with LPT = 2 up to ten seats (see lanes_for below for the measurements).  All integer arithmetic is the reference's; the fp32 reward keeps torch's
 // op order (no contraction; tanh rounded once from double).
 //
 // Memory: single step -- state is read once and only the words that changed are written back, in the reference's
@@ -741,11 +741,13 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
 }
 
 // ---------------------------------------------------------------- host side
-// lanes per table: four.  (The kernel is written for 2 or 4; two lanes per table -- half the replicated scalar work per
-// table, half the wavefronts -- was measured at 65,536 and 1,048,576 tables and lost both times: a wavefront's step is a
-// dependent chain whose length does not shrink with fewer lanes per table, and with half the wavefronts there is
-// less to overlap it with: 46.9 vs 43.6 us and 553 vs 463 us per 5-step chunk.  Not instantiated.)
-inline int lanes_for(const PulsePokerView&, bool) { return 4; }
+// Lanes per table.  Single-step launches: four.  Chunk launches: two where a lane can hold the table's seats in five
+// (max_players <= 10; PULSE_VIEW_FOUR_LANES asks for four), four otherwise.  Two lanes per table replicate the table's
+// scalar state machine half as often and issue half the wavefronts; measured per 5-step chunk (4 vs 2 lanes) at
+// 65,536 / 262,144 / 1,048,576 tables: 39.6 / 112.4 / 404 us vs 37.3 / 114.9 / 395 us.  (With this round's first chunk
+// kernel -- per-seat dword loads, library tanh, policy recomputed from the cards every step -- two lanes lost at every
+// size, 46.9 vs 43.6 us and 553 vs 463 us: what it saves is exactly the replicated table-level work those changes cut.)
+inline int lanes_for(const PulsePokerView& v, bool chunk) { return chunk && v.max_players <= 10 && !(v.flags & PULSE_VIEW_FOUR_LANES) ? 2 : 4; }
 inline dim3 step_grid(const PulsePokerView& v, int lpt) { return dim3((unsigned)(((long long)v.n_games * lpt + kStepBlock - 1) / kStepBlock)); }
 inline bool obs_staging(const PulsePokerView& v, const float* obs_odd, int lpt) {
     return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games % (64 / lpt)) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
@@ -788,7 +790,8 @@ void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor
 }
 
 void launch_chunk(const PulsePokerView& v, int64_t* actions, float* rewards_even, const PolicyArgs& pa, const ChunkArgs& ca, hipStream_t st) {
-    launch_any<PULSE_PH_STEP, true, true>(v, actions, nullptr, rewards_even, pa, ca, st);
+    if (lanes_for(v, true) == 2) launch_one<PULSE_PH_STEP, true, 2, 5, true>(v, actions, nullptr, rewards_even, pa, ca, st);
+    else launch_any<PULSE_PH_STEP, true, true>(v, actions, nullptr, rewards_even, pa, ca, st);
 }
 
 template <uint32_t PH>

@@ -220,7 +220,7 @@ def test_device_table_digest_matches_golden(golden_dir):
     assert hashlib.sha256(handranks.host_table().tobytes()).hexdigest() == str(vec["sha256"])
 
 
-@pytest.mark.parametrize("launcher", ["policy_step", "rollout", "rollout_per_step", "policy_then_step"])
+@pytest.mark.parametrize("launcher", ["policy_step", "rollout", "rollout_four_lanes", "rollout_per_step", "policy_then_step"])
 def test_fused_policy_step_matches_oracle(oracle_table, launcher):
     """Scripted opponents fused with the step (one launch) follow the oracle's policy+step trajectory
     bit for bit: same Philox stream, same masks (Player.py:79-176), same transition."""
@@ -230,6 +230,7 @@ def test_fused_policy_step_matches_oracle(oracle_table, launcher):
     kw = dict(n_players=P, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
     env = _gpu_env(seed=777, table_id0=5000, **kw)
     env.chunked_rollout = launcher != "rollout_per_step"
+    env.chunk_four_lanes = launcher == "rollout_four_lanes"      # default for 10 seats: two lanes per table
     ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
     types = [0, 3, 2, 2, 4, 3, 1, 4, 5, 3]      # seat 0 external (caller's action), the rest pokerGPU.yaml's mix
     rng = np.random.default_rng(3)
@@ -844,17 +845,20 @@ def test_rccl_exchange_with_one_rank_decides_like_the_local_rule():
 ROLLOUT_MEMORY = INT_KEYS + ("decks", "equities", "prev_stacks", "prev_invested", "equity_dirty")
 
 
-@pytest.mark.parametrize("N,P,MP", [(4096, 10, 10), (4099, 10, 10), (17, 6, 10), (1, 2, 2), (2048, 16, 16), (1040, 13, 16)],
-                         ids=["4096x10", "ragged4099", "17x6", "1x2", "2048x16", "1040x13of16"])
+@pytest.mark.parametrize("N,P,MP,four", [(4096, 10, 10, False), (4096, 10, 10, True), (4099, 10, 10, False), (4099, 10, 10, True), (17, 6, 10, False),
+                                          (1, 2, 2, False), (1, 2, 2, True), (2080, 12, 12, False), (2048, 16, 16, False), (1040, 13, 16, False)],
+                         ids=["4096x10", "4096x10-four-lanes", "ragged4099", "ragged4099-four-lanes", "17x6", "1x2", "1x2-four-lanes", "2080x12",
+                              "2048x16", "1040x13of16"])
 @pytest.mark.parametrize("dbl", [False, True], ids=["one-obs-buffer", "two-obs-buffers"])
-def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, dbl):
+def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, four, dbl):
     """pulse_poker_rollout as ONE launch per chunk (state in registers across the steps) against the same call issuing
-    one launch per step (PULSE_VIEW_NO_CHUNK): every state tensor, BOTH observation buffers, BOTH reward buffers, both
+    one launch per step (PULSE_VIEW_NO_CHUNK; always four lanes per table): every state tensor, BOTH observation buffers, BOTH reward buffers, both
     done buffers and the actions are bit-identical after every chunk -- chunk lengths 1..19 from odd and even step
     counters (the Philox pool of a chunk covers eight steps, longer chunks refill it), across episodes."""
     kw = dict(n_players=P, max_players=MP, n_games=N, w1=.5, w2=.3, K=100, alpha=50, seed=91, table_id0=7)
     one, per = _gpu_env(**kw), _gpu_env(**kw)
     per.chunked_rollout = False
+    one.chunk_four_lanes = four        # chunk launches: two lanes per table up to 10 seats (the default), four beyond / on request
     one.double_buffer_obs = per.double_buffer_obs = dbl
     types = ([0, 3, 2, 2, 4, 3, 1, 4, 5, 3, 1, 2, 3, 4, 5, 1])[:P]          # seat 0 external
     rng = np.random.default_rng(5)
