@@ -161,15 +161,6 @@ template <class T> __device__ __forceinline__ void sto_in_loop(T* base, uint32_t
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = val;
 }
 
-// ... and as a streaming (non-temporal) store: output that nobody on this GPU reads back before it has long left the
-// caches (the observation block) should not push the tables' state out of L2 between two launches.
-__device__ __forceinline__ void sto_in_loop_stream(int4* base, uint32_t byte_off, int4 val) {
-    asm volatile("" : "+v"(byte_off));
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i x; x.x = val.x; x.y = val.y; x.z = val.z; x.w = val.w;
-    __builtin_nontemporal_store(x, reinterpret_cast<v4i*>(reinterpret_cast<char*>(base) + byte_off));
-}
-
 // ---------------------------------------------------------------- DPP cross-lane steps (no LDS traffic)
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;                               // quad_perm:[1,0,3,2] / [2,3,0,1]

@@ -48,7 +48,6 @@ struct ChunkArgs {                         // MULTI only: the odd steps' output 
     float* obs_odd;
     float* rewards_odd;
     int n_steps;
-    int stream_obs = 0;                    // observation blocks leave as non-temporal stores
 };
 
 // In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
@@ -649,8 +648,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 const int tw0 = (int)((blockIdx.x * kStepBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
                 const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
                 const int4* src = reinterpret_cast<const int4*>(l_obs);
-                if (ca.stream_obs) { for (int e = wlane; e < n4; e += 64) sto_in_loop_stream(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]); }
-                else for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
+                for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
                 if (MULTI) {       // the next step's values must not overtake these reads of the slice
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -969,10 +967,9 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     if (chunk) {
         const PolicyArgs pa{packed, seed, step_counter0, table_id0, wave_done, carry.partials, carry.n, carry.host, carry.seq};
         ChunkArgs ca{v_odd->obs, rewards_odd, n_steps};
-        // while the batch's state still fits the caches (L2 + Infinity Cache) between two launches, the observation
-        // blocks -- 5 x 172 bytes per table and chunk that nobody here reads back -- leave as streaming stores so that
-        // they do not push it out: -1 % per chunk up to 262,144 tables, +4 % at 1,048,576 (measured both ways)
-        ca.stream_obs = v_even->n_games <= 262144 ? 1 : 0;
+        // (streaming, non-temporal observation stores were measured: -1 % per chunk up to 262,144 tables, +4 % at 1 M --
+        // and +50 % fabric write traffic, since ordinary stores to the two ping-pong blocks are largely absorbed by the
+        // caches.  Not used.)
         launch_chunk(*v_even, actions, rewards_even, pa, ca, st);
     } else {
         for (int i = 0; i < n_steps; ++i) {
