@@ -955,7 +955,8 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     if (v_even->n_games == 0 || n_steps == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t packed = pulse::pack_types(agent_types, v_even->n_players);
-    const bool chunk = !(v_even->flags & PULSE_VIEW_NO_CHUNK);
+    // one step is what the single-step kernel is for (15.4 vs 18.1 us at 65,536 tables: no LDS staging to amortise)
+    const bool chunk = !(v_even->flags & PULSE_VIEW_NO_CHUNK) && n_steps > 1;
     PulseTimer* tm = static_cast<PulseTimer*>(timer);
     const bool timed = tm && !tm->open && tm->used < PulseTimer::kMax;
     if (timed) if (int rc = timer_begin(tm, st)) return rc;
