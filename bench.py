@@ -139,6 +139,10 @@ class EpisodeLoop:
         self.native, q_seat, rotation = native_types_for_episode(self.episode)
         A = self.host_rng.randint(2, self.n_players)                  # PokerGPU.py:77 (host RNG: no .item() sync)
         self.env.reset(options={"rotation": rotation, "active_players": int(A), "q_agent_seat": q_seat})
+        # host-expensive follow-ups of the episode that just ended (a collective's enqueue) run while the GPU resets
+        after = getattr(self.on_episode_end, "after_reset", None)
+        if after is not None and self.episode > 0:
+            after(self)
         self.episode += 1
         self.steps_in_episode = 0
         self.rule.drain()
@@ -190,22 +194,32 @@ class EpisodeStatsReducer:
         self.collectives = 0
 
     def __call__(self, loop):
+        """At the boundary, BEFORE the reset: this episode's sums join the running totals (one small launch)."""
         import torch
         env = self.env
         env._lib.pulse_poker_stats(env.is_done.data_ptr(), env._rewards[0].data_ptr(), None, env.n_games, None,
                                    self.local.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        if self.world > 1 and self.work is not None:
+            self.work.wait()                         # stream-ordered for RCCL: the buffer is about to be rewritten
+            self.work = None
         if self.world > 1:
             import torch.distributed as dist
-            if self.work is not None:
-                self.work.wait()                     # stream-ordered for RCCL: the buffer is about to be rewritten
-            if dist.get_backend() == "gloo":         # one-GPU rehearsal: gloo reduces host copies
-                host = self.local.cpu()
-                dist.all_reduce(host)
-                self.reduced.copy_(host)
-            else:
+            if dist.get_backend() != "gloo":
                 self.reduced.copy_(self.local)
-                self.work = dist.all_reduce(self.reduced, async_op=True)
-            self.collectives += 1
+
+    def after_reset(self, loop):
+        """... and AFTER the reset was enqueued: the all-reduce (its enqueue costs the host tens of microseconds, which
+        the GPU spends resetting instead of waiting for the next episode's first launch)."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo":             # one-GPU rehearsal: gloo reduces host copies
+            host = self.local.cpu()
+            dist.all_reduce(host)
+            self.reduced.copy_(host)
+        else:
+            self.work = dist.all_reduce(self.reduced, async_op=True)
+        self.collectives += 1
 
     def totals(self):
         if self.work is not None:
