@@ -746,7 +746,9 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
 // scalar state machine half as often and issue half the wavefronts; measured per 5-step chunk (4 vs 2 lanes) at
 // 65,536 / 262,144 / 1,048,576 tables: 39.6 / 112.4 / 404 us vs 37.3 / 114.9 / 395 us.  (With this round's first chunk
 // kernel -- per-seat dword loads, library tanh, policy recomputed from the cards every step -- two lanes lost at every
-// size, 46.9 vs 43.6 us and 553 vs 463 us: what it saves is exactly the replicated table-level work those changes cut.)
+// size, 46.9 vs 43.6 us and 553 vs 463 us: what it saves is exactly the replicated table-level work those changes cut.
+// Tables of 12 / 16 seats at six / eight seats per lane were measured too and lose: 42.7 vs 42.5 and 72.6 vs 59.2 us at
+// 65,536 tables, 277 vs 233 and 391 vs 317 us at 524,288 -- registers (168 / 187) and LDS per wavefront grow with the seats.)
 inline int lanes_for(const PulsePokerView& v, bool chunk) { return chunk && v.max_players <= 10 && !(v.flags & PULSE_VIEW_FOUR_LANES) ? 2 : 4; }
 inline dim3 step_grid(const PulsePokerView& v, int lpt) { return dim3((unsigned)(((long long)v.n_games * lpt + kStepBlock - 1) / kStepBlock)); }
 inline bool obs_staging(const PulsePokerView& v, const float* obs_odd, int lpt) {
