@@ -148,6 +148,16 @@ __device__ __forceinline__ int rot_src(int k, int r, int c) {
     return r * NB + c;
 }
 
+// ... and the inverse: the cell (r*NB + c) of the k-times-rotated board whose source is cell i of the original
+template <int NB>
+__device__ __forceinline__ int rot_dst(int k, int i) {
+    int found = 0;
+    for (int r = 0; r < NB; ++r)
+        for (int c = 0; c < NB; ++c)
+            if (rot_src<NB>(k, r, c) == i) found = r * NB + c;
+    return found;
+}
+
 template <int NB>
 __device__ __forceinline__ void tfe_spawn(int (&b)[NB * NB], uint32_t r_cell, uint32_t r_val) {
     int ne = 0;
@@ -193,42 +203,58 @@ __global__ __launch_bounds__(kBlock) void tfe_step_kernel(int32_t* __restrict__ 
         const int k = (int)(actions[g] & 3);                                            // TFE.py:154
         int out[NB * NB];
         int score = 0;
-        // squash-left each row of the rotated board, writing straight back through the inverse
-        // permutation (TFE.py:158-178 without the buffer copies)
+        // The four moves are one squash-left on the board rotated k times (TFE.py:158-178).  The boards of a wavefront
+        // move in different directions, so four direction-specific copies of the squash would all be executed by every
+        // lane; instead the rotation itself is data: every cell of the rotated board is a two-level select among its
+        // four possible sources (3 v_cndmask per cell), ONE squash runs, and the inverse rotation is the same selects.
+        const bool k_odd = (k & 1) != 0, k_hi = (k & 2) != 0;
+        int rb[NB * NB];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk != k) continue;
+        for (int r = 0; r < NB; ++r)
 #pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                int res[NB];
+            for (int c = 0; c < NB; ++c) {
+                const int lo = k_odd ? b[rot_src<NB>(1, r, c)] : b[rot_src<NB>(0, r, c)];
+                const int hi = k_odd ? b[rot_src<NB>(3, r, c)] : b[rot_src<NB>(2, r, c)];
+                rb[r * NB + c] = k_hi ? hi : lo;
+            }
+        int sq[NB * NB];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) res[c] = 0;
-                int w = 0; bool last_merged = false;
+        for (int r = 0; r < NB; ++r) {
+            int res[NB];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {                                          // TFE.py:85-101
-                    const int val = b[rot_src<NB>(kk, r, c)];
-                    if (val != 0) {
-                        int cur = 0;
+            for (int c = 0; c < NB; ++c) res[c] = 0;
+            int w = 0; bool last_merged = false;
 #pragma unroll
-                        for (int x = 0; x < NB; ++x) cur = x == w ? res[x] : cur;
-                        if (cur == 0) {
+            for (int c = 0; c < NB; ++c) {                                              // TFE.py:85-101
+                const int val = rb[r * NB + c];
+                if (val != 0) {
+                    int cur = 0;
 #pragma unroll
-                            for (int x = 0; x < NB; ++x) if (x == w) res[x] = val;
-                        } else if (cur == val && !last_merged) {
+                    for (int x = 0; x < NB; ++x) cur = x == w ? res[x] : cur;
+                    if (cur == 0) {
 #pragma unroll
-                            for (int x = 0; x < NB; ++x) if (x == w) res[x] = val * 2;
-                            score += val * 2; last_merged = true;
-                        } else {
-                            w += 1;
+                        for (int x = 0; x < NB; ++x) if (x == w) res[x] = val;
+                    } else if (cur == val && !last_merged) {
 #pragma unroll
-                            for (int x = 0; x < NB; ++x) if (x == w) res[x] = val;
-                            last_merged = false;
-                        }
+                        for (int x = 0; x < NB; ++x) if (x == w) res[x] = val * 2;
+                        score += val * 2; last_merged = true;
+                    } else {
+                        w += 1;
+#pragma unroll
+                        for (int x = 0; x < NB; ++x) if (x == w) res[x] = val;
+                        last_merged = false;
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < NB; ++c) out[rot_src<NB>(kk, r, c)] = res[c];
             }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) sq[r * NB + c] = res[c];
+        }
+        // back: out[rot_src(k, r, c)] = sq[r][c], i.e. out[i] = sq[cell of the rotated board that came from i]
+#pragma unroll
+        for (int i = 0; i < NB * NB; ++i) {
+            const int lo = k_odd ? sq[rot_dst<NB>(1, i)] : sq[rot_dst<NB>(0, i)];
+            const int hi = k_odd ? sq[rot_dst<NB>(3, i)] : sq[rot_dst<NB>(2, i)];
+            out[i] = k_hi ? hi : lo;
         }
 #pragma unroll
         for (int i = 0; i < NB * NB; ++i) b[i] = out[i];
