@@ -23,7 +23,8 @@ the spread are in `config.blocks`.
 Launching: `python bench.py --gpus N` spawns N rank processes itself (this parent never touches the GPU);
 under torchrun (WORLD_SIZE set) the process is a rank.  Rank 0 prints ONE JSON line.  `roofline` prices the chunk
 kernel: algorithmic bytes per launch (453 B per table-step x tables x steps in the launch) over
-its mean duration from HIP event pairs recorded on the launch stream around every 4th launch of the timed blocks.
+its mean duration from HIP event pairs recorded on the launch stream around every launch of every 4th EPISODE of the
+timed blocks (whole episodes: a launch costs 0.55-1x the mean depending on the phase of the episode it falls in).
 `cpu_baseline` (N = 1 only) times the oracle (oracle/poker_oracle.c, the CPU restatement of the same policy + step +
 reset + shuffle, same seeds => the same games) in a short-lived child process of its own, so that no OpenMP pool ever
 lives in a process that holds the GPU.  `trainer_loop` (N = 1 only) is the second line SURVEY.md 8d asks for: the same
