@@ -8,6 +8,7 @@ set -e
 T="timeout -k 10 300"      # a profiled bench takes seconds; never let one hang the box
 TAG=${1:-r02}
 OUT=gpurun_out/$TAG
+rm -rf $OUT          # a second run into the same directory leaves two sets of CSVs per pass behind
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python bench.py --inproc --no-cpu-baseline --trainer-loop off"
