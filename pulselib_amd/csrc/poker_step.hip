@@ -34,9 +34,11 @@ namespace {
 constexpr int kStepBlock = PULSE_STEP_BLOCK;
 
 // dwords of LDS per wavefront of a chunk launch: the observation staging block + the staged read-only rows
-// (hole cards [16][P_][2], ranks [16][P_], street equities [16][3][P_], deck window [16][8], hand classes [16][P_]);
+// (hole cards [T][P_][2], 7-card rank | hand class << 16 [T][P_], flop and turn equities [T][2][P_], deck window [T][8]);
 // 16-byte aligned so that the observation block of the next wavefront is.
-__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables) { return (tables * (obs_size + seats * 7 + 8) + 3) & ~3; }
+// SLIM (MULTI == 2): the river's equities are not staged (they follow from the 7-card rank) and the hand class shares
+// a word with the rank: 5 instead of 7 dwords per seat, which is what lets three two-lane wavefronts per SIMD fit the LDS at large batches.
+__host__ __device__ constexpr int chunk_lds_dwords(int obs_size, int seats, int tables, bool slim) { return (tables * (obs_size + seats * (slim ? 5 : 7) + 8) + 3) & ~3; }
 
 struct PolicyArgs {
     uint64_t types_packed, seed, step_counter, table_id0;
@@ -109,7 +111,7 @@ template <int N_> struct alignas(4) SeatCells { int32_t v[N_]; };
 // workgroup barrier is involved.
 // MULTI: ca.n_steps steps in one launch (fused policy only); step i writes observation / done flag / reward into
 // the even (i even) or odd buffers, as n single launches on the two ping-pong views would.
-template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, bool MULTI>
+template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, int MULTI>
 __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
                                                            const int32_t* __restrict__ actor_idx_in,
                                                            float* __restrict__ rewards, const PolicyArgs pa, const ChunkArgs ca) {
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 load_cells(VEC, v.pre_hands, cell0, P, ph_, 0); load_cells(VEC, v.pre_rank, cell0, P, pr_, 0);
                 const int32_t* pe = reinterpret_cast<const int32_t*>(v.pre_eq);     // [N,3,P]: three rows of P per table
                 const uint32_t c0 = __umul24(ut * 3u, (uint32_t)P) + (uint32_t)(SPL * j);
-                load_cells(VEC, pe, c0, P, e1_, 0); load_cells(VEC, pe, c0 + (uint32_t)P, P, e2_, 0); load_cells(VEC, pe, c0 + 2u * (uint32_t)P, P, e3_, 0);
+                load_cells(VEC, pe, c0, P, e1_, 0); load_cells(VEC, pe, c0 + (uint32_t)P, P, e2_, 0);
+                if (MULTI != 2) load_cells(VEC, pe, c0 + 2u * (uint32_t)P, P, e3_, 0);          // (SLIM: the river row is not read)
             }
         }
     };
@@ -208,12 +211,14 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
     // previous step (the profile showed wavefronts parked there half of their life); LDS reads wait for nothing.
     constexpr int P_ = LPT * SPL;                                       // seats per table as staged (10, 12 or 16)
     const int wave = threadIdx.x >> 6, q = (threadIdx.x & 63) / LPT;     // wavefront of the workgroup, table of the wavefront
-    int32_t* const lw = reinterpret_cast<int32_t*>(smem4) + wave * chunk_lds_dwords(v.obs_size, P_, TPW);
+    constexpr bool SLIM = MULTI == 2;                                   // chunk for large batches: see chunk_lds_dwords
+    constexpr int EQROWS = SLIM ? 2 : 3;
+    int32_t* const lw = reinterpret_cast<int32_t*>(smem4) + wave * chunk_lds_dwords(v.obs_size, P_, TPW, SLIM);
     int32_t* const l_hands = lw + TPW * v.obs_size;                      // [TPW][P_][2]
-    int32_t* const l_prerank = l_hands + TPW * P_ * 2;                   // [TPW][P_]
-    float* const l_preeq = reinterpret_cast<float*>(l_prerank + TPW * P_);  // [TPW][3][P_]
-    int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + TPW * 3 * P_);  // [TPW][8]: cards at deck position dpos0 + 0..7
-    int32_t* const l_class = l_deck + TPW * 8;                            // [TPW][P_]: hand class of every seat (scripted players)
+    int32_t* const l_prerank = l_hands + TPW * P_ * 2;                   // [TPW][P_]: 7-card rank (SLIM: its 16 bits | hand class of the seat << 16)
+    float* const l_preeq = reinterpret_cast<float*>(l_prerank + TPW * P_);  // [TPW][EQROWS][P_]: flop, turn (and, not SLIM, river) equities
+    int32_t* const l_deck = reinterpret_cast<int32_t*>(l_preeq + TPW * EQROWS * P_);  // [TPW][8]: cards at deck position dpos0 + 0..7
+    int32_t* const l_class = l_deck + TPW * 8;                            // [TPW][P_] (not SLIM): hand class of every seat (scripted players)
     constexpr int DPL = 8 / LPT;                                         // deck-window entries each lane stages
     const int dpos0 = dpos;
     bool seat_hit[SPL];               // chunk: the cache entry of this lane's seat k was made from the hole cards it holds now
@@ -231,10 +236,10 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 cls = hand_class(-1, -1);
                 if (!empty) cls = hand_class(h0[k], h1[k]);
             }
-            l_class[q * P_ + seat] = (int32_t)cls;
-            l_prerank[q * P_ + seat] = pr_[k];
-            l_preeq[(q * 3 + 0) * P_ + seat] = __int_as_float(e1_[k]); l_preeq[(q * 3 + 1) * P_ + seat] = __int_as_float(e2_[k]);
-            l_preeq[(q * 3 + 2) * P_ + seat] = __int_as_float(e3_[k]);
+            if (SLIM) l_prerank[q * P_ + seat] = (int32_t)(((uint32_t)pr_[k] & 0xFFFFu) | cls << 16);      // a valid rank is below 2^16 (PokerGPU.py:13-18)
+            else { l_prerank[q * P_ + seat] = pr_[k]; l_class[q * P_ + seat] = (int32_t)cls; }
+            l_preeq[(q * EQROWS + 0) * P_ + seat] = __int_as_float(e1_[k]); l_preeq[(q * EQROWS + 1) * P_ + seat] = __int_as_float(e2_[k]);
+            if (!SLIM) l_preeq[(q * EQROWS + 2) * P_ + seat] = __int_as_float(e3_[k]);
         }
         const int32_t* dk = v.decks + (size_t)t * 52;
 #pragma unroll
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
     // carries these five values from one step to the next instead of picking them twice.
     int a_status = 0, a_stack = 0, a_bet = 0, a_h0 = 0, a_h1 = 0;
     uint32_t a_cls = 0;                  // chunk: the hand class of the seat to act instead of its two cards
-    auto class_of_seat = [&](int seat) -> uint32_t { return seat < P_ ? (uint32_t)l_class[q * P_ + seat] : hand_class(0, 0); };
+    auto class_of_seat = [&](int seat) -> uint32_t { return seat < P_ ? (SLIM ? (uint32_t)l_prerank[q * P_ + seat] >> 16 : (uint32_t)l_class[q * P_ + seat]) : hand_class(0, 0); };
     if (MULTI) {
         const int seat0 = idx & 15;
         a_status = SEAT_PICK(status, seat0); a_stack = SEAT_PICK(stack, seat0); a_bet = SEAT_PICK(bet, seat0);
@@ -380,7 +385,10 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                         if (cached_board) {       // the cache reads are independent single hops
                             if (MULTI) {
                                 hit = seat_hit[k];
-                                e = l_preeq[(q * 3 + (stage - 1)) * P_ + seat];
+                                if (SLIM && stage == 3) {      // the river's equity is the 7-card rank normalised (PokerGPU.py:481), as the reset kernel stored it
+                                    e = __fdiv_rn(__fsub_rn((float)(l_prerank[q * P_ + seat] & 0xFFFF), 4109.0f), 32765.0f);
+                                    e = fminf(fmaxf(e, 0.0f), 1.0f);
+                                } else e = l_preeq[(q * EQROWS + (stage - 1)) * P_ + seat];
                             } else {
                                 const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
                                 const float pe = ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                         if (cached_board) {
                             if (MULTI) {
                                 hit = seat_hit[k];
-                                rank[k] = l_prerank[q * P_ + seat];
+                                rank[k] = SLIM ? l_prerank[q * P_ + seat] & 0xFFFF : l_prerank[q * P_ + seat];
                             } else {
                                 const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
                                 hit = (ph & (kPreHandsValid * 2u - 1u)) == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
@@ -755,14 +763,14 @@ inline bool obs_staging(const PulsePokerView& v, const float* obs_odd, int lpt) 
     return !(v.flags & PULSE_VIEW_NO_OBS_STAGING) && (v.n_games % (64 / lpt)) == 0 && ((uintptr_t)v.obs & 15u) == 0 && ((uintptr_t)obs_odd & 15u) == 0;
 }
 
-template <uint32_t PH, bool POLICY, int LPT, int SPL, bool MULTI>
+template <uint32_t PH, bool POLICY, int LPT, int SPL, int MULTI>
 void launch_one(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, const ChunkArgs& ca,
                 hipStream_t st) {
     dim3 grid = step_grid(v, LPT);
     const dim3 block(kStepBlock);
     constexpr int TPW = 64 / LPT;
     const bool wobs = (PH & PULSE_PH_OBS) && (MULTI || PH == PULSE_PH_STEP) && obs_staging(v, MULTI ? ca.obs_odd : nullptr, LPT);
-    const size_t lds = MULTI ? sizeof(int32_t) * (size_t)(kStepBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, LPT * SPL, TPW)
+    const size_t lds = MULTI ? sizeof(int32_t) * (size_t)(kStepBlock / 64) * (size_t)chunk_lds_dwords(v.obs_size, LPT * SPL, TPW, MULTI == 2)
                              : (wobs ? sizeof(float) * (size_t)(kStepBlock / 64) * TPW * (size_t)v.obs_size : 0);
     constexpr bool W = PH == PULSE_PH_STEP;          // only the full step is instantiated with observation staging
     if (lds > 48 * 1024) {                           // beyond the default dynamic-LDS limit: raise it (to what this launch needs)
@@ -778,7 +786,7 @@ void launch_one(const PulsePokerView& v, int64_t* actions, const int32_t* actor_
     else hipLaunchKernelGGL((poker_step_kernel<PH, POLICY, LPT, SPL, false, MULTI>), grid, block, lds, st, v, actions, actor_idx, rewards, pa, ca);
 }
 
-template <uint32_t PH, bool POLICY, bool MULTI>
+template <uint32_t PH, bool POLICY, int MULTI>
 void launch_any(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, const ChunkArgs& ca,
                 hipStream_t st) {
     // seats per lane must cover max_players (the observation's padding slots too)
@@ -788,12 +796,17 @@ void launch_any(const PulsePokerView& v, int64_t* actions, const int32_t* actor_
 
 template <uint32_t PH, bool POLICY>
 void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor_idx, float* rewards, const PolicyArgs& pa, hipStream_t st) {
-    launch_any<PH, POLICY, false>(v, actions, actor_idx, rewards, pa, ChunkArgs{nullptr, nullptr, 1}, st);
+    launch_any<PH, POLICY, 0>(v, actions, actor_idx, rewards, pa, ChunkArgs{nullptr, nullptr, 1}, st);
 }
 
 void launch_chunk(const PulsePokerView& v, int64_t* actions, float* rewards_even, const PolicyArgs& pa, const ChunkArgs& ca, hipStream_t st) {
-    if (lanes_for(v, true) == 2) launch_one<PULSE_PH_STEP, true, 2, 5, true>(v, actions, nullptr, rewards_even, pa, ca, st);
-    else launch_any<PULSE_PH_STEP, true, true>(v, actions, nullptr, rewards_even, pa, ca, st);
+    if (lanes_for(v, true) == 2) {
+        // large batches: the slim LDS image (three wavefronts per SIMD instead of 2.5: 364 vs 403 us per chunk at 1 M
+        // tables); where all the wavefronts of the batch are resident anyway it only costs the river's divisions
+        // (38.0 vs 37.2 us at 65,536 tables)
+        if (v.n_games > 196608) launch_one<PULSE_PH_STEP, true, 2, 5, 2>(v, actions, nullptr, rewards_even, pa, ca, st);
+        else launch_one<PULSE_PH_STEP, true, 2, 5, 1>(v, actions, nullptr, rewards_even, pa, ca, st);
+    } else launch_any<PULSE_PH_STEP, true, 1>(v, actions, nullptr, rewards_even, pa, ca, st);
 }
 
 template <uint32_t PH>
