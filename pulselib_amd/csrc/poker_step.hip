@@ -801,10 +801,11 @@ void launch_step(const PulsePokerView& v, int64_t* actions, const int32_t* actor
 
 void launch_chunk(const PulsePokerView& v, int64_t* actions, float* rewards_even, const PolicyArgs& pa, const ChunkArgs& ca, hipStream_t st) {
     if (lanes_for(v, true) == 2) {
-        // large batches: the slim LDS image (three wavefronts per SIMD instead of 2.5: 364 vs 403 us per chunk at 1 M
-        // tables); where all the wavefronts of the batch are resident anyway it only costs the river's divisions
-        // (38.0 vs 37.2 us at 65,536 tables)
-        if (v.n_games > 196608) launch_one<PULSE_PH_STEP, true, 2, 5, 2>(v, actions, nullptr, rewards_even, pa, ca, st);
+        // The full LDS image lets 10 two-lane wavefronts live on a CU (2.5 per SIMD = 81,920 tables on the 256 CUs of an
+        // MI355X), the slim one 12.  Batches with more wavefronts than that take the slim image -- 67.0 vs 68.9 us per chunk
+        // at 131,072 tables, 84.9 vs 91.8 at 196,608, 361 vs 403 at 1,048,576; where every wavefront is resident anyway it
+        // only costs the river's divisions (37.7 vs 37.2 us at 65,536 tables).
+        if (v.n_games > 81920) launch_one<PULSE_PH_STEP, true, 2, 5, 2>(v, actions, nullptr, rewards_even, pa, ca, st);
         else launch_one<PULSE_PH_STEP, true, 2, 5, 1>(v, actions, nullptr, rewards_even, pa, ca, st);
     } else launch_any<PULSE_PH_STEP, true, 1>(v, actions, nullptr, rewards_even, pa, ca, st);
 }
