@@ -846,15 +846,18 @@ ROLLOUT_MEMORY = INT_KEYS + ("decks", "equities", "prev_stacks", "prev_invested"
 
 
 @pytest.mark.parametrize("N,P,MP,four", [(4096, 10, 10, False), (4096, 10, 10, True), (4099, 10, 10, False), (4099, 10, 10, True), (17, 6, 10, False),
-                                          (1, 2, 2, False), (1, 2, 2, True), (2080, 12, 12, False), (2048, 16, 16, False), (1040, 13, 16, False)],
+                                          (1, 2, 2, False), (1, 2, 2, True), (2080, 12, 12, False), (2048, 16, 16, False), (1040, 13, 16, False),
+                                          (98304, 10, 10, False)],
                          ids=["4096x10", "4096x10-four-lanes", "ragged4099", "ragged4099-four-lanes", "17x6", "1x2", "1x2-four-lanes", "2080x12",
-                              "2048x16", "1040x13of16"])
+                              "2048x16", "1040x13of16", "98304x10-slim-lds-image"])
 @pytest.mark.parametrize("dbl", [False, True], ids=["one-obs-buffer", "two-obs-buffers"])
 def test_chunked_rollout_leaves_the_memory_of_single_launches(N, P, MP, four, dbl):
     """pulse_poker_rollout as ONE launch per chunk (state in registers across the steps) against the same call issuing
     one launch per step (PULSE_VIEW_NO_CHUNK; always four lanes per table): every state tensor, BOTH observation buffers, BOTH reward buffers, both
     done buffers and the actions are bit-identical after every chunk -- chunk lengths 1..19 from odd and even step
-    counters (the Philox pool of a chunk covers eight steps, longer chunks refill it), across episodes."""
+    counters (the Philox pool of a chunk covers eight steps, longer chunks refill it), across episodes.  Above 81,920
+    tables the chunk kernel stages a slim image of the read-only rows (river equities recomputed from the rank): the
+    98,304-table case."""
     kw = dict(n_players=P, max_players=MP, n_games=N, w1=.5, w2=.3, K=100, alpha=50, seed=91, table_id0=7)
     one, per = _gpu_env(**kw), _gpu_env(**kw)
     per.chunked_rollout = False
