@@ -67,6 +67,7 @@ template <bool SHUFFLE>
 __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerView v, const PulsePokerResetOpts o) {
     __shared__ uint32_t keys[kBlock / kLanes][52];
     __shared__ int32_t deck_s[kBlock / kLanes][52];
+    __shared__ uint8_t valid_s[kBlock / kLanes];          // the table's 2A+5 cards are distinct and in 1..52 (its cache entry can be made)
     const int gt = blockIdx.x * kBlock + threadIdx.x;
     const int t = gt >> 4, s = gt & 15, g = threadIdx.x >> 4;
     if (t >= v.n_games) return;
@@ -144,32 +145,10 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         const bool board_ok = card_ok(f0) && card_ok(f1) && card_ok(f2) && card_ok(f3) && card_ok(f4);
         m |= (1ull << (f0 & 63)) | (1ull << (f1 & 63)) | (1ull << (f2 & 63)) | (1ull << (f3 & 63)) | (1ull << (f4 & 63));
         const bool valid = !bad && board_ok && __popcll(m) == 2 * A + 5;    // 2A+5 distinct cards in 1..52
-        const int32_t* __restrict__ hr = v.hand_ranks;
-        const uint32_t hr_len = (uint32_t)v.hand_ranks_len;
-        if (valid && inA) {
-            // For distinct valid cards the table walk returns the closed-form hand value (hand_eval_device.h -- the
-            // evaluator the table is generated from), so the three streets are computed instead of gathered: flop =
-            // HR[value of the 5 cards] (:521 reads the table once more at the value itself: its hot first 150 KB),
-            // turn = value of the 6 cards (:500), river / showdown = value of the 7 (:437-444).
-            HandAcc acc;
-            hand_add(acc, h0); hand_add(acc, h1); hand_add(acc, f0); hand_add(acc, f1); hand_add(acc, f2);
-            const int v5 = hand_value(acc);
-            hand_add(acc, f3);
-            const int v6 = hand_value(acc);
-            hand_add(acc, f4);
-            const int r7 = hand_value(acc);
-            const float vf = (float)hr_at_nb(hr, hr_len, v5);                               // :521
-            const float vt = (float)v6;                                                     // :500
-            float ef = __fdiv_rn(__fsub_rn(vf, 74359.0f), 749420.0f);                       // :523
-            float et = __fdiv_rn(__fsub_rn(vt, 4109.0f), 32765.0f);                         // :502
-            float er = __fdiv_rn(__fsub_rn((float)r7, 4109.0f), 32765.0f);                  // :481
-            ef = fminf(fmaxf(ef, 0.0f), 1.0f); et = fminf(fmaxf(et, 0.0f), 1.0f); er = fminf(fmaxf(er, 0.0f), 1.0f);
-            float* pe = v.pre_eq + (size_t)t * 3 * P;
-            pe[s] = ef; pe[P + s] = et; pe[2 * P + s] = er;
-            v.pre_rank[row] = r7;
-        }
-        // hole-card tag + the scripted players' class of the hand (poker_device.h: hand_class), both fixed for the episode
-        if (seat) v.pre_hands[row] = (valid && inA) ? (int32_t)(pack_hand(h0, h1) | hand_class(h0, h1) << kClsShift) : 0;
+        // the per-seat part of the cache (three hand values, tag, class) is computed at the end of the kernel, by as many
+        // threads of the workgroup as there are seats in its hands; seats outside the hand get an empty tag here
+        if (s == 0) valid_s[g] = valid ? 1 : 0;
+        if (seat && !(valid && inA)) v.pre_hands[row] = 0;
         if (s == 0) v.pre_board[t] = valid ? (int32_t)(pack_board(f0, f1, f2, f3, f4) | kPreBoardValid) : 0;
     }
     const int button = o.first ? 0 : pymod(v.button[t] + 1, A);                         // :121
@@ -210,6 +189,48 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         else k = s - 1;
         float* dst = ob + 13 + 3 * k;
         dst[0] = f0; dst[1] = f1; dst[2] = f2;
+    }
+
+    // ---- evaluation cache, per seat.  In the mapping above (16 lanes per table) only A of a table's 16 lanes hold a seat
+    // of the hand, yet every wavefront would run the evaluator (~450 vector instructions) whatever A is.  The decks of the
+    // workgroup's tables sit in LDS, so the (table, seat) pairs are dealt to the workgroup's threads in order instead:
+    // 16 A pairs -- one wavefront for A <= 4, two for A <= 8, ... -- and the wavefronts beyond skip all of it.
+    // (Wavefronts of tables past the end of the batch have left; the barrier counts only those still running.)
+    if (!v.pre_board) return;
+    __syncthreads();
+    const int t_first = blockIdx.x * (kBlock / kLanes);
+    const int tables_here = min(kBlock / kLanes, v.n_games - t_first);
+    const int e = (int)threadIdx.x;
+    if ((e & ~63) >= tables_here * A) return;                                   // the whole wavefront has no pair
+    const int tb = (e * (65536 / A + 1)) >> 16, se = e - tb * A;                 // e / A, e % A (exact for e < 256, A <= 16)
+    if (tb >= tables_here || !valid_s[tb]) return;
+    {
+        const int c0 = deck_s[tb][2 * se], c1 = deck_s[tb][2 * se + 1];
+        const int f0 = deck_s[tb][2 * A + 1], f1 = deck_s[tb][2 * A + 2], f2 = deck_s[tb][2 * A + 3];
+        const int f3 = deck_s[tb][2 * A + 5], f4 = deck_s[tb][2 * A + 7];
+        // For distinct valid cards the table walk returns the closed-form hand value (hand_eval_device.h -- the
+        // evaluator the table is generated from), so the three streets are computed instead of gathered: flop =
+        // HR[value of the 5 cards] (:521 reads the table once more at the value itself: its hot first 150 KB),
+        // turn = value of the 6 cards (:500), river / showdown = value of the 7 (:437-444).
+        HandAcc acc;
+        hand_add(acc, c0); hand_add(acc, c1); hand_add(acc, f0); hand_add(acc, f1); hand_add(acc, f2);
+        const int v5 = hand_value(acc);
+        hand_add(acc, f3);
+        const int v6 = hand_value(acc);
+        hand_add(acc, f4);
+        const int r7 = hand_value(acc);
+        const float vf = (float)hr_at_nb(v.hand_ranks, (uint32_t)v.hand_ranks_len, v5);   // :521
+        const float vt = (float)v6;                                                     // :500
+        float ef = __fdiv_rn(__fsub_rn(vf, 74359.0f), 749420.0f);                       // :523
+        float et = __fdiv_rn(__fsub_rn(vt, 4109.0f), 32765.0f);                         // :502
+        float er = __fdiv_rn(__fsub_rn((float)r7, 4109.0f), 32765.0f);                  // :481
+        ef = fminf(fmaxf(ef, 0.0f), 1.0f); et = fminf(fmaxf(et, 0.0f), 1.0f); er = fminf(fmaxf(er, 0.0f), 1.0f);
+        const size_t tt = (size_t)(t_first + tb);
+        float* pe = v.pre_eq + tt * 3 * P;
+        pe[se] = ef; pe[P + se] = et; pe[2 * P + se] = er;
+        v.pre_rank[tt * P + se] = r7;
+        // hole-card tag + the scripted players' class of the hand (poker_device.h: hand_class), both fixed for the episode
+        v.pre_hands[tt * P + se] = (int32_t)(pack_hand(c0, c1) | hand_class(c0, c1) << kClsShift);
     }
 }
 
