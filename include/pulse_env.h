@@ -221,6 +221,11 @@ int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t
 int pulse_stoprule_decide(void* handle, int32_t* over);
 int pulse_stoprule_drain(void* handle);
 int pulse_stoprule_destroy(void* handle);
+/* How the handle exchanges its counts: 0 = local (one process), 1 = RCCL side stream (any communicator, also of one
+ * rank), 2 = shared memory; side_launches = check points that went through the side stream so far (tests assert the
+ * RCCL leg really ran). */
+int pulse_stoprule_mode(void* handle);
+int64_t pulse_stoprule_side_launches(void* handle);
 
 /* The shared-memory exchange of the stop rule as an object of its own (host code only; the rule creates one itself when
  * given shm_name).  Every rank maps the POSIX segment `name` (created by whoever comes first; unlink it once all ranks

@@ -103,6 +103,8 @@ SYMBOLS = {
     "pulse_stoprule_decide": (C.c_int, [_P, _P]),
     "pulse_stoprule_drain": (C.c_int, [_P]),
     "pulse_stoprule_destroy": (C.c_int, [_P]),
+    "pulse_stoprule_mode": (C.c_int, [_P]),
+    "pulse_stoprule_side_launches": (_I64, [_P]),
     "pulse_shm_create": (C.c_int, [C.c_char_p, _I32, _I32, _P]),
     "pulse_shm_all_sum": (C.c_int, [_P, _I64, _I64, _P]),
     "pulse_shm_destroy": (C.c_int, [_P]),

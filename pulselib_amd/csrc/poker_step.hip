@@ -155,8 +155,9 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
 #define SEAT(k) (SPL * j + (k))
 #define ROW_OFF(k) ((row0 + (uint32_t)SEAT(k)) * 4u)                   /* byte offset of (table, seat) in an [N,P] int32 array */
     const uint32_t cell0 = row0 + (uint32_t)(SPL * j), ecell0 = eq0 + (uint32_t)(SPL * j);     // this lane's first cell
-    const bool vec_ok = cell0 + (uint32_t)SPL <= __umul24((uint32_t)v.n_games, (uint32_t)P) &&
-                        ecell0 + (uint32_t)SPL <= __umul24((uint32_t)v.n_games, (uint32_t)A);   // (implies the same for hands and pre_eq)
+    // (plain 32-bit multiplies: n_games may be 2^24 itself, which a 24-bit multiply truncates to 0)
+    const bool vec_ok = cell0 + (uint32_t)SPL <= (uint32_t)v.n_games * (uint32_t)P &&
+                        ecell0 + (uint32_t)SPL <= (uint32_t)v.n_games * (uint32_t)A;   // (implies the same for hands and pre_eq)
     // VEC = std::true_type: one vector load; std::false_type: cell by cell.  `limit` = seats that exist in the row.
     auto load_cells = [&](auto VEC, const int32_t* base, uint32_t first_cell, int limit, int (&out)[SPL], int fill) {
         SeatCells<SPL> c;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
             if (cache_on) {
                 load_cells(VEC, v.pre_hands, cell0, P, ph_, 0); load_cells(VEC, v.pre_rank, cell0, P, pr_, 0);
                 const int32_t* pe = reinterpret_cast<const int32_t*>(v.pre_eq);     // [N,3,P]: three rows of P per table
-                const uint32_t c0 = __umul24(ut * 3u, (uint32_t)P) + (uint32_t)(SPL * j);
+                const uint32_t c0 = __umul24(ut, 3u * (uint32_t)P) + (uint32_t)(SPL * j);     // (ut * 3 leaves 24 bits above 5.59 M tables; 3 P <= 48 does not)
                 load_cells(VEC, pe, c0, P, e1_, 0); load_cells(VEC, pe, c0 + (uint32_t)P, P, e2_, 0);
                 if (MULTI != 2) load_cells(VEC, pe, c0 + 2u * (uint32_t)P, P, e3_, 0);          // (SLIM: the river row is not read)
             }
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                                 } else e = l_preeq[(q * EQROWS + (stage - 1)) * P_ + seat];
                             } else {
                                 const uint32_t ph = (uint32_t)ldo(v.pre_hands, ROW_OFF(k));
-                                const float pe = ldo(v.pre_eq, (__umul24(ut * 3u + (uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
+                                const float pe = ldo(v.pre_eq, (__umul24(ut, 3u * (uint32_t)P) + __umul24((uint32_t)(stage - 1), (uint32_t)P) + (uint32_t)seat) * 4u);
                                 hit = (ph & (kPreHandsValid * 2u - 1u)) == pack_hand(h0[k], h1[k]) && card_ok(h0[k]) && card_ok(h1[k]);
                                 e = pe;
                             }
@@ -1009,6 +1010,8 @@ int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView
                               void* stoprule, void* stream, int32_t* steps_done, int32_t* over) {
     if (!steps_done || !over || chunk_steps <= 0 || max_steps < 0 || !stoprule)
         return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout_until: bad argument");
+    if (int rc = pulse::check_view(v_even, "pulse_poker_rollout_until")) return rc;
+    if (int rc = pulse::check_view(v_odd, "pulse_poker_rollout_until")) return rc;
     PulseTimer* tm = static_cast<PulseTimer*>(timer);
     hipStream_t st = (hipStream_t)stream;
     const bool per_step = (v_even->flags & PULSE_VIEW_NO_CHUNK) != 0;

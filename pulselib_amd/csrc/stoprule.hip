@@ -14,6 +14,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -153,7 +154,12 @@ extern "C" {
 int pulse_shm_create(const char* name, int32_t rank, int32_t world, void** out) {
     if (!name || !out || world < 1 || rank < 0 || rank >= world) return pulse::fail(PULSE_EINVAL, "pulse_shm_create: bad argument");
     PulseShm* h = new PulseShm{nullptr, (size_t)world * kSlots * sizeof(ShmRecord), rank, world};
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    // Whoever comes first creates the segment (O_EXCL: a fresh, zero-filled one, seq 0 = nothing published); the others
+    // open it.  A stale segment of that name (a crashed job whose rank-0 pid was reused) would carry old sequence
+    // numbers: the host code removes the name before it tells the ranks (stoprule.py: _shared_name), and the name
+    // carries a time stamp besides the pid.
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 && errno == EEXIST) fd = shm_open(name, O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)h->bytes) != 0) { if (fd >= 0) close(fd); delete h; return pulse::fail(PULSE_EINTERNAL, "pulse_shm_create: shm_open / ftruncate failed"); }
     void* m = mmap(nullptr, h->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
@@ -214,6 +220,7 @@ struct PulseStopRule {
     PulseComm* comm; hipStream_t side; hipEvent_t ready[kSlots], copied[kSlots];
     // shared-memory exchange
     PulseShm* shm; int rank, world;
+    long long side_launches;              // check points that went through the side stream (sum -> all-reduce -> publish)
 };
 
 namespace {
@@ -256,10 +263,11 @@ int stoprule_claim(PulseStopRule* h, int n_partials, uint32_t** partials_out, St
     if (n_partials <= 0 || n_partials > h->max_partials) return fail(PULSE_EINVAL, "stop rule: too many partial counts for this handle");
     const int slot = (int)(h->submitted % kSlots);
     // the slot's previous occupant (kSlots check points ago) must have been consumed: its verdict was due lag + 1 <= kSlots submissions ago
+    if (!partials_out || !carry) return fail(PULSE_EINVAL, "stop rule: null argument");
     *partials_out = h->partials_dev + (size_t)slot * h->max_partials;
     *carry = StopRuleCarry{nullptr, 0, nullptr, 0};
     const long long prev = h->submitted - 1;
-    if (carry && h->mode != kModeRccl && prev >= 0 && h->scheduled < prev + 1) {
+    if (h->mode != kModeRccl && prev >= 0 && h->scheduled < prev + 1) {
         const int ps = (int)(prev % kSlots);
         *carry = StopRuleCarry{h->partials_dev + (size_t)ps * h->max_partials, h->n_partials[ps], reinterpret_cast<long long*>(h->host + ps), prev + 1};
         h->scheduled = prev + 1;
@@ -285,6 +293,7 @@ int stoprule_commit(PulseStopRule* h, int n_partials, hipStream_t st) {
         if (e == hipSuccess) e = hipEventRecord(h->copied[slot], h->side);
         if (e != hipSuccess) return fail_hip((int)e, "stop rule: publish to host");
         h->scheduled = h->submitted + 1;
+        ++h->side_launches;
     }
     ++h->submitted;
     return 0;
@@ -302,7 +311,9 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
     std::memset(h, 0, sizeof *h);
     h->n_local = n_local; h->n_global = n_global; h->threshold = threshold; h->lag = lag;
     h->comm = static_cast<PulseComm*>(comm); h->rank = rank; h->world = world;
-    h->mode = (h->comm && h->comm->world > 1) ? kModeRccl : (shm_name && world > 1) ? kModeShm : kModeLocal;
+    // a communicator is honoured whatever its size: a world of one is a valid all-reduce, and it is what a one-GPU box
+    // can run of the side-stream path (event hand-over, sum, ncclAllReduce, publish)
+    h->mode = h->comm ? kModeRccl : (shm_name && world > 1) ? kModeShm : kModeLocal;
     h->max_partials = (int)(((long long)n_local * 4 + 63) / 64) + 4;          // one per wavefront of a step launch (4 lanes per table at most)
     if (h->max_partials < kMaxPartials) h->max_partials = kMaxPartials;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->partials_dev), (size_t)kSlots * h->max_partials * sizeof(uint32_t));
@@ -315,7 +326,13 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
             if (e == hipSuccess) e = hipEventCreateWithFlags(&h->copied[i], hipEventDisableTiming);
         }
     }
-    if (e != hipSuccess) { delete h; return pulse::fail_hip((int)e, "pulse_stoprule_create"); }
+    if (e != hipSuccess) {                      // release whatever was created (destroy tolerates the missing pieces)
+        const int code = pulse::fail_hip((int)e, "pulse_stoprule_create");
+        (void)hipGetLastError();
+        h->submitted = 0; h->last_stream = nullptr;
+        (void)pulse_stoprule_destroy(h);
+        return code;
+    }
     std::memset(h->host, 0, kSlots * sizeof(Published));
     if (h->mode == kModeShm) {
         void* shm = nullptr;
@@ -330,16 +347,29 @@ int pulse_stoprule_destroy(void* handle) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!h) return 0;
     if (h->mode == kModeRccl) {
-        (void)hipStreamSynchronize(h->side);
-        for (int i = 0; i < kSlots; ++i) { (void)hipEventDestroy(h->ready[i]); (void)hipEventDestroy(h->copied[i]); }
-        (void)hipStreamDestroy(h->side);
+        if (h->side) (void)hipStreamSynchronize(h->side);
+        for (int i = 0; i < kSlots; ++i) { if (h->ready[i]) (void)hipEventDestroy(h->ready[i]); if (h->copied[i]) (void)hipEventDestroy(h->copied[i]); }
+        if (h->side) (void)hipStreamDestroy(h->side);
     } else if (h->last_stream || h->submitted) {
         (void)hipStreamSynchronize(h->last_stream);       // a launch may still be about to write into the pinned block
     }
     if (h->shm) (void)pulse_shm_destroy(h->shm);
-    (void)hipFree(h->partials_dev); (void)hipFree(h->pair_dev); (void)hipHostFree(h->host);
+    if (h->partials_dev) (void)hipFree(h->partials_dev);
+    if (h->pair_dev) (void)hipFree(h->pair_dev);
+    if (h->host) (void)hipHostFree(h->host);
     delete h;
     return 0;
+}
+
+int pulse_stoprule_mode(void* handle) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_mode: null argument");
+    return h->mode;
+}
+
+int64_t pulse_stoprule_side_launches(void* handle) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    return h ? h->side_launches : -1;
 }
 
 int pulse_stoprule_submit(void* handle, const uint8_t* flags, int32_t n, void* stream) {

@@ -41,11 +41,16 @@ class Particle2D(_EnvBase):
         self.terminated = torch.zeros(batch_size, device=device, dtype=torch.bool)
         self.steps = torch.zeros(batch_size, device=device, dtype=torch.int32)
         self._truncated = torch.zeros(batch_size, device=device, dtype=torch.bool)     # constant (Particle2D.py:30)
-        # step() returns fresh tensors in the reference (state.clone(), :26-30); here two persistent sets alternate, so
-        # what a step returned stays intact through the NEXT step and no allocation happens per call
-        self._out = [(torch.empty((batch_size, 4), device=device), torch.empty(batch_size, device=device),
-                      torch.empty(batch_size, device=device, dtype=torch.bool)) for _ in range(2)]
+        # step() returns fresh tensors, as the reference does (state.clone(), Particle2D.py:26-30): a caller may keep a
+        # trajectory of them.  `reuse_outputs = True` (opt-in, like PokerGPU.double_buffer_obs) alternates two persistent
+        # output sets instead: what a step returned then stays intact through the NEXT step only, no allocation per call.
+        self.reuse_outputs = False
+        self._out = None
         self._pp = 0
+
+    def _new_outputs(self):
+        return (torch.empty((self.batch_size, 4), device=self.device), torch.empty(self.batch_size, device=self.device),
+                torch.empty(self.batch_size, device=self.device, dtype=torch.bool))
 
     def reset(self, seed=None, options=None):                       # Particle2D.py:15-20
         if seed is not None:
@@ -63,8 +68,13 @@ class Particle2D(_EnvBase):
         if not (isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.device == self.device and action.is_contiguous()):
             action = torch.as_tensor(action, dtype=torch.float32).to(self.device).contiguous()
         assert action.shape == (self.batch_size, 2)
-        obs, rewards, terminated = self._out[self._pp]
-        self._pp ^= 1
+        if self.reuse_outputs:
+            if self._out is None:
+                self._out = [self._new_outputs() for _ in range(2)]
+            obs, rewards, terminated = self._out[self._pp]
+            self._pp ^= 1
+        else:
+            obs, rewards, terminated = self._new_outputs()          # (torch's caching allocator: no hipMalloc per call)
         _native.check(self._lib.pulse_particle2d_step(self.state.data_ptr(), action.data_ptr(), self.steps.data_ptr(),
                                                       obs.data_ptr(), rewards.data_ptr(), terminated.data_ptr(),
                                                       self.batch_size, float(self.dt), int(self.max_steps),

@@ -193,15 +193,26 @@ class LaggedDoneCount:
 
     @classmethod
     def _shared_name(cls, device, group):
-        """A segment name all ranks agree on: rank 0 picks it (its pid + a counter), the group broadcasts 8 bytes."""
+        """A segment name all ranks agree on: rank 0 picks it (its pid + a counter + a time stamp), removes whatever a
+        crashed job may have left under that name (a stale segment would carry old sequence numbers), and only then
+        broadcasts the 24 bytes -- no rank can open the name before it has been cleared."""
+        import time
         import torch.distributed as dist
         cls._shm_counter += 1
-        ident = torch.tensor([os.getpid(), cls._shm_counter], dtype=torch.int64)
+        ident = torch.tensor([os.getpid(), cls._shm_counter, time.time_ns() & ((1 << 40) - 1)], dtype=torch.int64)
+        if dist.get_rank(group) == 0:
+            try:
+                os.unlink("/dev/shm" + cls._name_of(*ident.tolist()))
+            except OSError:
+                pass
         if dist.get_backend(group) == "nccl":
             ident = ident.to(torch.device(device))
         dist.broadcast(ident, src=0, group=group)
-        pid, k = (int(x) for x in ident.cpu().tolist())
-        return f"/pulse_stoprule_{pid}_{k}"
+        return cls._name_of(*(int(x) for x in ident.cpu().tolist()))
+
+    @staticmethod
+    def _name_of(pid, k, stamp):
+        return f"/pulse_stoprule_{pid}_{k}_{stamp:x}"
 
     def submit(self, flags: torch.Tensor) -> None:
         """One check point: count the set flags of `flags` (bool/uint8[n]) in stream order.
@@ -243,6 +254,17 @@ class LaggedDoneCount:
         _native.check(self._lib.pulse_stoprule_decide(self.handle, C.byref(flag)), "pulse_stoprule_decide")
         self.decisions += 1
         return bool(flag.value)
+
+    @property
+    def native_mode(self) -> str | None:
+        """What the native handle does with a check point's count: 'local', 'rccl' (side stream) or 'shm'."""
+        if self.handle is None:
+            return None
+        return ("local", "rccl", "shm")[self._lib.pulse_stoprule_mode(self.handle)]
+
+    @property
+    def side_stream_check_points(self) -> int:
+        return int(self._lib.pulse_stoprule_side_launches(self.handle)) if self.handle is not None else 0
 
     def drain(self) -> None:
         """Episode boundary: the chunks submitted so far decide nothing any more."""

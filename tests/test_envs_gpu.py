@@ -148,6 +148,29 @@ def test_particle2d_hip_matches_oracle_one_million():
         np.testing.assert_array_equal(_np(term), rterm)
 
 
+def test_particle2d_step_outputs_are_fresh_unless_reuse_is_asked_for():
+    """The reference returns new tensors from every step (state.clone(), Particle2D.py:26-30): a caller may keep them.
+    Default: no output of an earlier step is ever rewritten.  reuse_outputs (opt-in): two persistent sets alternate, so
+    an output survives exactly one further step."""
+    from pulselib_amd.environments.Particle2D import Particle2D
+    B = 4096
+    env = Particle2D(torch.device(DEV), B)
+    env.reset(seed=3)
+    a = torch.rand((B, 2), device=DEV) * 2 - 1
+    kept = [env.step(a)[:3] for _ in range(4)]
+    copies = [[x.clone() for x in k] for k in kept]
+    env.step(a)
+    assert len({k[0].data_ptr() for k in kept}) == 4
+    for k, c in zip(kept, copies):
+        assert all(torch.equal(x, y) for x, y in zip(k, c))
+    env.reuse_outputs = True
+    o1 = env.step(a)[0]; c1 = o1.clone()
+    o2 = env.step(a)[0]
+    assert torch.equal(o1, c1) and o2.data_ptr() != o1.data_ptr()
+    o3 = env.step(a)[0]
+    assert o3.data_ptr() == o1.data_ptr() and not torch.equal(o3, c1)
+
+
 def _pack_board(b):
     key = 0
     for i, v in enumerate(b.reshape(-1)):

@@ -821,6 +821,8 @@ def test_rccl_exchange_with_one_rank_decides_like_the_local_rule():
         ra = LaggedDoneCount(dev, N, 0.8, lag=1, n_global=N, exchange="rccl", comm=comm)
         rb = LaggedDoneCount(dev, N, 0.8, lag=1)
         assert ra.exchange == "rccl" and rb.exchange == "local"
+        # the native handle really is in RCCL mode with a one-rank communicator (round 2 silently fell back to local)
+        assert ra.native_mode == "rccl" and rb.native_mode == "local"
         types = [1, 3, 2, 4, 5, 1]
         acts = [torch.zeros(N, dtype=torch.long, device=dev) for _ in range(2)]
         gstep, fired = 0, False
@@ -836,6 +838,8 @@ def test_rccl_exchange_with_one_rank_decides_like_the_local_rule():
             for name in ("stacks", "status", "pots", "stages", "idx", "is_done"):
                 np.testing.assert_array_equal(to_np(getattr(a, name)), to_np(getattr(b, name)), err_msg=f"episode {e} {name}")
         assert fired
+        # every check point went through the side stream: event hand-over, sum kernel, ncclAllReduce, publish kernel
+        assert ra.side_stream_check_points == gstep // 5 and rb.side_stream_check_points == 0, (ra.side_stream_check_points, gstep)
         ra.close(); rb.close(); comm.close()
     finally:
         if own_group:
