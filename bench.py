@@ -15,10 +15,13 @@ Steps are counted like the reference: n_tables x step calls, finished tables inc
 inside the timed region and are not counted.  The roll-out enqueues a 5-step chunk as ONE launch
 (pulse_poker_rollout: state in registers across the steps, every step's observation / reward / done / action stored).
 
-`--steps K --warmup W`: W untimed steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
-sides and max-reduced over the ranks.  A 20-step block is ~0.1 ms, so the block is repeated (`config.repeats`) until
-the blocks sum to >= 50 ms and span >= 8 episodes; `ms_per_step` / `value` come from the MEDIAN block, the mean and
-the spread are in `config.blocks`.
+`--steps K --warmup W`: W untimed steps, then blocks of EXACTLY K steps: barrier, synchronize, clock, K steps, synchronize,
+clock -- the closing barrier comes AFTER the clock is read (an 8-rank barrier is an all-reduce + host sync, tens of
+microseconds: inside a 0.2 ms block it would be a "scaling loss" made by the stopwatch); the block's time is the MAX
+over the ranks.  A 20-step block is ~0.2 ms, so the block is repeated (`config.repeats`) until the blocks sum to >= 1 s
+of GPU time and span >= 8 episodes; `ms_per_step` / `value` come from the MEDIAN block, the mean and the spread are in
+`config.blocks`.  Two workloads are timed: `active_players` sampled 2..10 per episode as the
+reference's trainer does (`value`), and forced to 10 (`active_players_10`, with its own roofline).
 
 Launching: `python bench.py --gpus N` spawns N rank processes itself (this parent never touches the GPU);
 under torchrun (WORLD_SIZE set) the process is a rank.  Rank 0 prints ONE JSON line.  `roofline` prices the chunk
@@ -26,9 +29,13 @@ kernel: algorithmic bytes per launch (453 B per table-step x tables x steps in t
 its mean duration from HIP event pairs recorded on the launch stream around every launch of every 4th EPISODE of the
 timed blocks (whole episodes: a launch costs 0.55-1x the mean depending on the phase of the episode it falls in).
 `cpu_baseline` (N = 1 only) times the oracle (oracle/poker_oracle.c, the CPU restatement of the same policy + step +
-reset + shuffle, same seeds => the same games) in a short-lived child process of its own, so that no OpenMP pool ever
+reset + shuffle, same seeds => the same games; tests/test_poker_gpu_parity.py holds the two legs to the same episode
+lengths, done counts and reward sums) in a short-lived child process of its own, so that no OpenMP pool ever
 lives in a process that holds the GPU.  `trainer_loop` (N = 1 only) is the second line SURVEY.md 8d asks for: the same
-environment with the learner (PokerQNetwork) acting and training every step.
+environment with the learner (PokerQNetwork) acting and training every step, at 65,536 tables and at the 2,000,000 the
+reference's published run used.  `other_envs` (N = 1 only): 2048 step, its tabular Q-learning roll-out step, Particle2D
+and Blackjack at BASELINE.json's sizes, each against its HBM roofline and with an oracle-port CPU baseline.
+`finished_tables` (N = 1 only): the share of the counted table-steps that ran on tables already finished.
 """
 from __future__ import annotations
 
@@ -54,6 +61,7 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CHECK_INTERVAL = 5                  # trainGPU.py:31
 TERMINATION_THRESHOLD = 0.8         # trainGPU.py:76
 SEED = 20260401
+KERNEL_SOURCES = ("pulselib_amd/csrc/poker_step.hip", "pulselib_amd/csrc/poker_device.h")   # what the chunk kernel is compiled from
 
 
 def parse_args(argv=None):
@@ -62,14 +70,17 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU (weak scaling)")
+    ap.add_argument("--active-players", choices=["both", "sampled", "10"], default="both",
+                    help="sampled: 2..10 per episode like the reference's trainer (= `value`); 10: every seat in every hand "
+                         "(the P = 10 case the 453 B/step figure prices); both: `value` from sampled, a sub-record for 10")
     ap.add_argument("--stop-rule", choices=["lagged", "sync"], default="lagged")
     ap.add_argument("--max-episode-steps", type=int, default=40,
                     help="episode cap: the reference's close-on-aggressor rule livelocks tables whose last ACTIVE seat "
                          "keeps calling against all-ins (SURVEY.md A.3), so >20 %% of tables may never finish; its "
                          "published runs average 31-35 steps per episode (results/PokerGPU/runs/run_2..8.yaml)")
-    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="repeat the K-step block until the blocks sum to this")
+    ap.add_argument("--min-timed-ms", type=float, default=1000.0, help="repeat the K-step block until the blocks sum to this")
     ap.add_argument("--min-episodes", type=int, default=8, help="... and span at least this many episodes")
-    ap.add_argument("--max-repeats", type=int, default=4000)
+    ap.add_argument("--max-repeats", type=int, default=20000)
     ap.add_argument("--per-step-launches", action="store_true", help="one launch per step instead of one per chunk (A/B)")
     ap.add_argument("--stop-exchange", choices=["auto", "host", "shm", "rccl"], default="auto",
                     help="how the ranks exchange the stop rule's counts (auto: shared memory with the nccl backend, torch.distributed with gloo)")
@@ -77,6 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--trainer-loop", choices=["auto", "on", "off"], default="auto", help="auto: at N = 1")
     ap.add_argument("--trainer-episodes", type=int, default=12)
+    ap.add_argument("--trainer-tables-large", type=int, default=2000000, help="second trainer-loop size (the reference's published N_GAMES); 0 = skip")
+    ap.add_argument("--other-envs", choices=["auto", "on", "off"], default="auto", help="2048 / Q-learning / Particle2D / Blackjack records; auto: at N = 1")
+    ap.add_argument("--census", choices=["auto", "on", "off"], default="auto", help="share of table-steps on finished tables; auto: at N = 1")
     ap.add_argument("--role", choices=["launcher", "rank", "cpu"], default="launcher", help=argparse.SUPPRESS)
     ap.add_argument("--inproc", action="store_true", help="measure in this process (what a profiler wraps); same as --role rank")
     return ap.parse_args(argv)
@@ -110,6 +124,12 @@ def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')} pid {os.getpid()}] {msg}", file=sys.stderr, flush=True)
 
 
+def sample_active_players(host_rng, mode, n_players=10):
+    """`active_players` of the next episode: PokerGPU.py:77 draws randint(2, n_players + 1) on the device and syncs; here
+    a host RNG (no .item() sync), or the fixed 10 of the second workload."""
+    return host_rng.randint(2, n_players) if mode == "sampled" else int(mode)
+
+
 # ------------------------------------------------------------------------------------------------ episode loop
 # The kernel timer (HIP events on the launch stream) brackets every chunk launch of every TIME_EVERY-th EPISODE, whole
 # episodes only: a launch costs 0.55x..1x of the mean depending on the phase of the episode it falls in, so brackets
@@ -125,11 +145,12 @@ class EpisodeLoop:
     per-episode statistics all-reduce).  Every rank of a job makes the same sequence of calls: the stop verdicts come
     from the job-wide count at a fixed lag, everything else is a function of (episode, host RNG seed)."""
 
-    def __init__(self, env, rule, actions, max_episode_steps, on_episode_end=None, host_seed=0, n_players=10):
+    def __init__(self, env, rule, actions, max_episode_steps, on_episode_end=None, host_seed=0, n_players=10, active_players="sampled"):
         self.env, self.rule, self.actions = env, rule, actions
         self.max_episode_steps, self.on_episode_end = max_episode_steps, on_episode_end
         self.host_rng = random.Random(host_seed)
         self.n_players = n_players
+        self.active_mode = active_players
         self.episode = 0
         self.global_step = 0           # Philox offset of the scripted policies
         self.steps_in_episode = 0
@@ -138,7 +159,7 @@ class EpisodeLoop:
 
     def new_episode(self):
         self.native, q_seat, rotation = native_types_for_episode(self.episode)
-        A = self.host_rng.randint(2, self.n_players)                  # PokerGPU.py:77 (host RNG: no .item() sync)
+        A = sample_active_players(self.host_rng, self.active_mode, self.n_players)
         self.env.reset(options={"rotation": rotation, "active_players": int(A), "q_agent_seat": q_seat})
         # host-expensive follow-ups of the episode that just ended (a collective's enqueue) run while the GPU resets
         after = getattr(self.on_episode_end, "after_reset", None)
@@ -198,7 +219,8 @@ class EpisodeStatsReducer:
         """At the boundary, BEFORE the reset: this episode's sums join the running totals (one small launch)."""
         import torch
         env = self.env
-        env._lib.pulse_poker_stats(env.is_done.data_ptr(), env._rewards[0].data_ptr(), None, env.n_games, None,
+        last_rewards = env._rewards[1 - env._pp]          # the set the episode's last step wrote (step i of a call writes set (pp + i) % 2)
+        env._lib.pulse_poker_stats(env.is_done.data_ptr(), last_rewards.data_ptr(), None, env.n_games, None,
                                    self.local.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
         if self.world > 1 and self.work is not None:
             self.work.wait()                         # stream-ordered for RCCL: the buffer is about to be rewritten
@@ -231,48 +253,64 @@ class EpisodeStatsReducer:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (child)
-def cpu_baseline(args):
-    """Oracle (CPU restatement) timed on the host cores over a bounded sample of the same workload: same seeds, same
-    Philox decks, same scripted-opponent draws, same `active_players` sequence and rotation as the GPU leg."""
+def cpu_episode_trace(n_tables, max_episodes, lag, max_episode_steps, threads, seconds=None, active_players="sampled", table_id0=0):
+    """The GPU leg's episodes on the oracle (CPU restatement): same seeds, same Philox decks, same scripted-opponent draws,
+    same `active_players` sequence and rotation, the stop rule of trainGPU.py:27-33 at the same fixed lag.  Returns one
+    record per episode {steps, done, reward_sum, seconds}; stops after `max_episodes` or once `seconds` of CPU time are
+    spent.  (tests/test_poker_gpu_parity.py compares these records with the GPU leg's.)"""
     import numpy as np
     from oracle import oracle as orc
-    n_tables = args.tables
-    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     env = orc.OraclePokerEnv(n_players=10, max_players=10, n_games=n_tables, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3,
                              K=100, alpha=50, n_threads=threads)
     host_rng = random.Random(0)
     actions = np.zeros(n_tables, dtype=np.int64)
-    total_steps, elapsed, episode, gstep = 0, 0.0, 0, 0
-    while elapsed < args.cpu_seconds and episode < 5000:
+    out, elapsed, gstep = [], 0.0, 0
+    for episode in range(max_episodes):
+        if seconds is not None and elapsed >= seconds:
+            break
         native, q_seat, rotation = native_types_for_episode(episode)
-        A = host_rng.randint(2, 10)
+        A = sample_active_players(host_rng, active_players)
         t0 = time.perf_counter()
-        decks = orc.shuffle_decks(SEED, 0, episode, n_tables)        # what the reset kernel draws for (seed, table, episode)
+        decks = orc.shuffle_decks(SEED, table_id0, episode, n_tables)        # what the reset kernel draws for (seed, table, episode)
         env.reset(options={"rotation": rotation, "active_players": A, "q_agent_seat": q_seat, "prefixed_decks": decks})
         idx, verdicts = 0, []
         while True:
-            env.policy_step(native, SEED, gstep, actions)
+            env.policy_step(native, SEED, gstep, actions, table_id0=table_id0)
             gstep += 1
             idx += 1
             if idx % CHECK_INTERVAL == 0:
                 verdicts.append(env.is_done.mean() > TERMINATION_THRESHOLD)
-                lag = 0 if args.stop_rule == "sync" else 1
                 if len(verdicts) > lag and verdicts[-1 - lag]:          # the GPU leg's fixed-lag rule
                     break
-            if idx >= args.max_episode_steps:
+            if idx >= max_episode_steps:
                 break
-        elapsed += time.perf_counter() - t0
-        total_steps += idx * n_tables
-        episode += 1
-    return {"value": total_steps / elapsed, "unit": "env-steps/sec", "cores": threads, "kind": "port",
-            "sample": f"{episode} episodes x {n_tables} tables, {total_steps} table-steps in {elapsed:.1f} s "
-                      f"(oracle/poker_oracle.c shuffle+reset+policy+step, OpenMP over tables, same seeds / decks / draws / "
-                      f"active_players sequence as the GPU leg, stop rule as trainGPU.py:27-33 one check late, "
-                      f"cap {args.max_episode_steps} steps/episode)"}
+        dt = time.perf_counter() - t0
+        elapsed += dt
+        out.append({"steps": idx, "done": int(env.is_done.sum()), "reward_sum": float(env.rewards.astype(np.float64).sum()), "seconds": dt})
+    return out
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement) timed on the host cores over a bounded sample of the same workload."""
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    mode = "10" if args.active_players == "10" else "sampled"
+    trace = cpu_episode_trace(args.tables, 5000, 0 if args.stop_rule == "sync" else 1, args.max_episode_steps, threads,
+                              seconds=args.cpu_seconds, active_players=mode)
+    total_steps = sum(e["steps"] for e in trace) * args.tables
+    elapsed = sum(e["seconds"] for e in trace)
+    out = {"value": total_steps / elapsed, "unit": "env-steps/sec", "cores": threads, "kind": "port",
+           "sample": f"{len(trace)} episodes x {args.tables} tables, {total_steps} table-steps in {elapsed:.1f} s "
+                     f"(oracle/poker_oracle.c shuffle+reset+policy+step, OpenMP over tables, same seeds / decks / draws / "
+                     f"active_players sequence ({mode}) as the GPU leg, stop rule as trainGPU.py:27-33 one check late, "
+                     f"cap {args.max_episode_steps} steps/episode)"}
+    if args.other_envs != "off":
+        from tools.bench_envs import cpu_records
+        out["other_envs"] = cpu_records(seconds_each=3.0)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ trainer loop leg
-def trainer_loop_leg(args, device):
+def trainer_loop_leg(args, device, tables):
     """The second line of SURVEY.md 8d: the reference trainer's loop (scripts/Poker/trainGPU.py:57-108) -- the learner
     acting and training every step -- on the native path (scripts/trainGPU.py: train_agent_fused)."""
     import torch
@@ -284,44 +322,128 @@ def trainer_loop_leg(args, device):
                       seed=SEED)
     agents.insert(0, q)
     types.insert(0, PokerAgentType.QLEARNING)
-    env = PokerGPU(device=device, agents=agents, n_players=10, max_players=10, n_games=args.tables, starting_bbs=100, max_bbs=1000,
+    env = PokerGPU(device=device, agents=agents, n_players=10, max_players=10, n_games=tables, starting_bbs=100, max_bbs=1000,
                    w1=.5, w2=.3, K=100, alpha=50, seed=SEED)
     kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=False)
-    train_agent_fused(env, agents, types, 2, args.tables, device, **kw)          # warm-up episodes
+    episodes = args.trainer_episodes if tables <= 262144 else max(3, args.trainer_episodes // 3)
+    train_agent_fused(env, agents, types, 2, tables, device, **kw)          # warm-up episodes
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = train_agent_fused(env, agents, types, args.trainer_episodes, args.tables, device, **kw)
+    out = train_agent_fused(env, agents, types, episodes, tables, device, **kw)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    steps = out["total_steps"] // args.tables
+    steps = out["total_steps"] // tables
+    del env, q, agents
+    torch.cuda.empty_cache()
     return {"value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "ms_per_step": elapsed / max(steps, 1) * 1e3,
-            "tables": args.tables, "episodes": args.trainer_episodes, "steps": steps,
+            "tables": tables, "episodes": episodes, "steps": steps,
             "learner": "PokerQNetwork 40-128-128-64-32-13, fp32 MFMA kernels (act, train, reduce, AdamW), acting and training every step",
             "counts_as": "n_games x steps incl. finished tables (trainGPU.py:108), episodes timed end to end incl. resets and the per-episode read-back",
             "reference_published": {"value": 2.5e7, "tables": 2000000, "hardware": "unnamed CUDA GPU",
-                                    "source": "results/PokerGPU/runs/run_2.yaml:35 (BASELINE.md section 1)"}}
+                                    "source": "results/PokerGPU/runs/run_2.yaml:21,35 (BASELINE.md section 1)"}}
+
+
+# ------------------------------------------------------------------------------------------------ census
+def finished_tables_census(args, device, episodes=8):
+    """How many of the counted table-steps ran on tables that were already finished (the reference counts them,
+    trainGPU.py:108; so do we).  The first `episodes` episodes of the sampled workload replayed with one launch per
+    step (bit-identical to the chunks: tests) so that the done flags can be summed before every step; the stop rule is
+    the timed loop's."""
+    import torch
+    from pulselib_amd.environments.Poker import PokerGPU
+    from pulselib_amd.stoprule import LaggedDoneCount
+    N = args.tables
+    env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000,
+                   w1=.5, w2=.3, K=100, alpha=50, seed=SEED)
+    rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1)
+    host_rng = random.Random(0)
+    actions = torch.zeros(N, dtype=torch.long, device=device)
+    before = torch.zeros((), dtype=torch.int64, device=device)
+    gstep, lengths, at_end = 0, [], []
+    for e in range(episodes):
+        native, q_seat, rotation = native_types_for_episode(e)
+        env.reset(options={"rotation": rotation, "active_players": sample_active_players(host_rng, "sampled"), "q_agent_seat": q_seat})
+        rule.drain()
+        idx = 0
+        while True:
+            for i in range(CHECK_INTERVAL):
+                before += env.is_done.sum()
+                env.rollout(native, actions, 1, gstep, stop_rule=rule if i == CHECK_INTERVAL - 1 else None)
+                gstep += 1
+                idx += 1
+            if rule.over() or idx >= args.max_episode_steps:
+                break
+        lengths.append(idx)
+        at_end.append(int(env.is_done.sum()))
+    rule.close()
+    total = N * sum(lengths)
+    return {"share_of_counted_table_steps_on_finished_tables": int(before) / total, "episodes": episodes, "episode_steps": lengths,
+            "tables_done_at_episode_end": at_end, "tables": N,
+            "note": "finished tables are stepped and counted as the reference does (trainGPU.py:108: total_steps += n_games * idx); "
+                    "a step on a finished table still writes its observation, reward (0) and done flag"}
 
 
 # ------------------------------------------------------------------------------------------------ one rank
-def recorded_traffic(tables, steps_per_launch):
-    """HBM-side bytes per launch of the chunk kernel from the newest committed rocprofv3 PMC summary
-    (profiles/rNN/step_kernel_profile.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected by the
-    dword-stream calibration recorded with them).  None if no summary matches this workload."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile.json")):
+def _sha_of_kernel_sources():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(tables, steps_per_launch, active_players):
+    """HBM-side bytes per launch of the chunk kernel.  NOT measured in this run (PMC counters need rocprofv3): read from
+    the newest committed summary (profiles/rNN/step_kernel_profile*.json: FETCH_SIZE / WRITE_SIZE in separate passes,
+    corrected by the dword-stream calibration recorded with them) that matches this workload AND was collected from the
+    kernel source this build was compiled from (sha256 over KERNEL_SOURCES recorded at collection time); otherwise None
+    with the reason.  Returns (bytes or None, source string)."""
+    want_sha = _sha_of_kernel_sources()
+    best, why = None, "no profiles/r*/step_kernel_profile*.json matches this workload"
+    for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile*.json")):
         try:
             d = json.loads(f.read_text())
-            if int(d.get("tables_per_launch", -1)) == tables and int(d.get("steps_per_launch", 1)) == steps_per_launch:
-                best = float(d["traffic_bytes_per_launch"])
+            if int(d.get("tables_per_launch", -1)) != tables or int(d.get("steps_per_launch", 1)) != steps_per_launch:
+                continue
+            if str(d.get("active_players", "sampled")) != str(active_players):
+                continue
+            rel = str(f.relative_to(ROOT))
+            if d.get("kernel_source_sha256_16") != want_sha:
+                why = f"stale: {rel} was collected from other kernel sources ({d.get('kernel_source_sha256_16')} != {want_sha}); re-run tools/collect_profiles.sh"
+                continue
+            best, why = float(d["traffic_bytes_per_launch"]), rel
         except Exception:
             pass
-    return best
+    return (best, why) if best is not None else (None, why)
+
+
+def roofline_record(args, N, sum_ms, n_launches, n_steps_timed, active_players):
+    if n_launches <= 0:
+        return None
+    kernel_s = sum_ms * 1e-3 / n_launches
+    steps_per_launch = n_steps_timed / n_launches
+    alg = BYTES_PER_TABLE_STEP * N * steps_per_launch
+    achieved = alg / kernel_s / 1e9
+    traffic, source = recorded_traffic(N, int(round(steps_per_launch)), active_players)
+    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": source,
+           "traffic_GBps": None if traffic is None else traffic / kernel_s / 1e9,
+           "traffic_frac": None if traffic is None else traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
+           "kernel": "poker_step_kernel<PH_STEP, POLICY, MULTI>" if not args.per_step_launches else "poker_step_kernel<PH_STEP, POLICY>",
+           "kernel_us": kernel_s * 1e6, "launches_timed": n_launches, "steps_per_launch": steps_per_launch,
+           "algorithmic_bytes_per_launch": alg,
+           "note": "achieved / frac price ALGORITHMIC bytes (453 B per table-step, SURVEY.md 8d, x tables x steps per launch) as the "
+                   "bench contract asks; a chunk keeps the state in registers between its steps, so the bytes that really cross "
+                   "the fabric (traffic, from the committed rocprofv3 counter summary named in traffic_source -- a file constant, "
+                   "not measured in this run) are about half of that: traffic_frac is the kernel's real HBM utilisation. "
+                   "The kernel is bound by instruction issue / dependent latency, not by HBM (DESIGN.md section 6)"}
+    return rec
 
 
 def main_rank(args):
     import faulthandler
     # a bench that takes minutes is a bug: dump every thread's stack and exit instead of hanging the box
-    faulthandler.dump_traceback_later(int(os.environ.get("PULSE_BENCH_WATCHDOG_S", "360")), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("PULSE_BENCH_WATCHDOG_S", "480")), exit=True)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -370,81 +492,99 @@ def main_rank(args):
     env.chunked_rollout = not args.per_step_launches
     rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world,
                            exchange=None if args.stop_exchange == "auto" else args.stop_exchange)
-    stats = EpisodeStatsReducer(env, device, world)
     actions = torch.zeros(N, dtype=torch.long, device=device)
-    loop = EpisodeLoop(env, rule, actions, args.max_episode_steps, on_episode_end=stats)
     timer = RolloutTimer()
-    if rank == 0:
-        _log(f"environment ready ({N} tables/GPU x {world}, stop-rule exchange: {rule.exchange}); warm-up {args.warmup} steps ...")
-    loop.run_steps(args.warmup)
-    torch.cuda.synchronize()
-    timer.collect()
-    if rank == 0:
-        _log(f"timing blocks of {args.steps} steps ...")
 
-    blocks, episodes0 = [], loop.episode
-    while True:
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ran = loop.run_steps(args.steps, timer=timer, time_every=TIME_EVERY)
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        assert ran == args.steps
-        blocks.append(max_over_ranks(dt))               # identical on every rank: so is the decision below
-        enough = sum(blocks) * 1e3 >= args.min_timed_ms and loop.episode - episodes0 >= args.min_episodes
-        if enough or len(blocks) >= args.max_repeats:
-            break
-    sum_ms, n_launches, n_steps_timed = timer.collect()
-    episodes_timed = loop.episode - episodes0
-    if rank == 0:
-        _log(f"timed region done: {len(blocks)} blocks, {sum(blocks) * 1e3:.1f} ms")
-
-    trainer = None
-    if args.trainer_loop == "on" or (args.trainer_loop == "auto" and world == 1):
+    def measure(mode):
+        """Warm-up, then blocks of exactly args.steps steps: barrier -> sync -> t0 -> steps -> sync -> dt; the MAX over
+        the ranks of dt is the block's time.  No collective and no barrier between the two clock reads."""
+        stats = EpisodeStatsReducer(env, device, world)
+        loop = EpisodeLoop(env, rule, actions, args.max_episode_steps, on_episode_end=stats, active_players=mode)
         if rank == 0:
-            _log("trainer-loop leg ...")
-        del loop, env
-        trainer = trainer_loop_leg(args, device)
+            _log(f"active_players {mode}: warm-up {args.warmup} steps ...")
+        loop.run_steps(args.warmup)
+        torch.cuda.synchronize()
+        timer.collect()
         if rank == 0:
-            _log(f"trainer loop: {trainer['value']:.3g} env-steps/s")
-
-    if rank == 0:
+            _log(f"active_players {mode}: timing blocks of {args.steps} steps ...")
+        blocks, episodes0 = [], loop.episode
+        while True:
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ran = loop.run_steps(args.steps, timer=timer, time_every=TIME_EVERY)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0              # read BEFORE anything collective
+            assert ran == args.steps
+            blocks.append(max_over_ranks(dt))           # identical on every rank: so is the decision below
+            enough = sum(blocks) * 1e3 >= args.min_timed_ms and loop.episode - episodes0 >= args.min_episodes
+            if enough or len(blocks) >= args.max_repeats:
+                break
+        sum_ms, n_launches, n_steps_timed = timer.collect()
         med = statistics.median(blocks)
         total_tables = N * world
-        roofline = None
-        if n_launches > 0:
-            kernel_s = sum_ms * 1e-3 / n_launches
-            steps_per_launch = n_steps_timed / n_launches
-            alg = BYTES_PER_TABLE_STEP * N * steps_per_launch
-            achieved = alg / kernel_s / 1e9
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": recorded_traffic(N, int(round(steps_per_launch))),
-                        "kernel": "poker_step_kernel<PH_STEP, POLICY, MULTI>" if not args.per_step_launches else "poker_step_kernel<PH_STEP, POLICY>",
-                        "kernel_us": kernel_s * 1e6, "launches_timed": n_launches, "steps_per_launch": steps_per_launch,
-                        "algorithmic_bytes_per_launch": alg,
-                        "note": "algorithmic bytes = 453 B per table-step (SURVEY.md 8d) x tables x steps the launch processes; "
-                                "a chunk re-reads no state between its steps, so HBM traffic per launch is below this figure"}
+        rec = {"active_players": "sampled 2..10 per episode (host RNG seeded 0)" if mode == "sampled" else "10 in every episode",
+               "value": total_tables * args.steps / med, "ms_per_step": med / args.steps * 1e3,
+               "repeats": len(blocks), "episodes_timed": loop.episode - episodes0,
+               "blocks": {"median_ms": med * 1e3, "mean_ms": statistics.fmean(blocks) * 1e3, "min_ms": min(blocks) * 1e3,
+                          "max_ms": max(blocks) * 1e3, "sum_ms": sum(blocks) * 1e3,
+                          "value_from_mean": total_tables * args.steps / statistics.fmean(blocks)},
+               "episode_stats": stats.totals(),
+               "roofline": roofline_record(args, N, sum_ms, n_launches, n_steps_timed, mode) if rank == 0 else None}
+        if rank == 0:
+            _log(f"active_players {mode}: {len(blocks)} blocks, {sum(blocks) * 1e3:.1f} ms, {rec['value']:.4g} env-steps/s")
+        return rec
+
+    if rank == 0:
+        _log(f"environment ready ({N} tables/GPU x {world}, stop-rule exchange: {rule.exchange})")
+    modes = ["sampled", "10"] if args.active_players == "both" else [args.active_players]
+    records = {m: measure(m) for m in modes}
+    main = records[modes[0]]
+
+    trainer = census = other = None
+    solo = world == 1
+    if args.census == "on" or (args.census == "auto" and solo):
+        if rank == 0:
+            _log("finished-tables census ...")
+            census = finished_tables_census(args, device)
+    if args.trainer_loop == "on" or (args.trainer_loop == "auto" and solo):
+        del env
+        torch.cuda.empty_cache()
+        sizes = [args.tables] + ([args.trainer_tables_large] if args.trainer_tables_large and args.trainer_tables_large != args.tables else [])
+        trainer = []
+        for tables in sizes:
+            if rank == 0:
+                _log(f"trainer-loop leg, {tables} tables ...")
+            trainer.append(trainer_loop_leg(args, device, tables))
+            if rank == 0:
+                _log(f"trainer loop: {trainer[-1]['value']:.3g} env-steps/s")
+    if (args.other_envs == "on" or (args.other_envs == "auto" and solo)) and rank == 0:
+        _log("other environments ...")
+        from tools.bench_envs import gpu_records
+        other = gpu_records(device)
+
+    if rank == 0:
+        def workload(mode):
+            return (f"Poker {N} tables/GPU x {world} GPU, 10 seats, config/pokerGPU.yaml opponents, env-only (policy+step fused, "
+                    f"5-step chunks), device-shuffled decks, active_players {'sampled 2..10' if mode == 'sampled' else '10'}")
         out = {
-            "metric": "env-steps/sec (whole node), Poker batched tables", "value": total_tables * args.steps / med, "unit": "env-steps/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": med / args.steps * 1e3,
+            "metric": "env-steps/sec (whole node), Poker batched tables", "value": main["value"], "unit": "env-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"Poker {N} tables/GPU x {world} GPU, 10 seats, config/pokerGPU.yaml opponents, "
-                                   f"env-only (policy+step fused, 5-step chunks), device-shuffled decks, active_players 2..10",
+            "config": {"workload": workload(modes[0]),
                        "tables_per_gpu": N, "n_players": 10, "stop_rule": args.stop_rule, "stop_rule_exchange": rule.exchange,
                        "max_episode_steps": args.max_episode_steps, "steps_per_launch": CHECK_INTERVAL if not args.per_step_launches else 1,
-                       "repeats": len(blocks), "episodes_timed": episodes_timed,
-                       "blocks": {"median_ms": med * 1e3, "mean_ms": statistics.fmean(blocks) * 1e3, "min_ms": min(blocks) * 1e3,
-                                  "max_ms": max(blocks) * 1e3, "sum_ms": sum(blocks) * 1e3,
-                                  "value_from_mean": total_tables * args.steps / statistics.fmean(blocks)},
-                       "episode_stats": stats.totals(),
+                       "repeats": main["repeats"], "episodes_timed": main["episodes_timed"], "blocks": main["blocks"],
+                       "episode_stats": main["episode_stats"], "min_timed_ms": args.min_timed_ms,
+                       "timed_window": "barrier, sync, t0, K steps, sync, dt (no barrier or collective between the clock reads); MAX over ranks",
                        "parallelism": f"tables sharded x{world}, no data-path collective; stop-rule count + episode statistics all-reduced"},
-            "roofline": roofline, "trainer_loop": trainer,
+            "roofline": main["roofline"], "trainer_loop": trainer, "finished_tables": census, "other_envs": other,
         }
+        if len(modes) > 1:
+            sub = dict(records[modes[1]])
+            sub["workload"] = workload(modes[1])
+            out["active_players_10"] = sub
         print(json.dumps(out), flush=True)
-    else:
-        stats.totals()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -545,6 +685,10 @@ def launcher(args, argv):
         ok = not timed_out and all(p.returncode == 0 for p in procs) and lines
         if ok:
             line = json.loads(lines[-1])
+            if cpu and cpu.get("other_envs") is not None:           # the child's per-environment CPU samples join their GPU records
+                per_env = cpu.pop("other_envs")
+                for rec in line.get("other_envs") or []:
+                    rec["cpu_baseline"] = per_env.get(rec.get("name"))
             line["cpu_baseline"] = cpu
             line["attempts"] = attempt
             print(json.dumps(line), flush=True)

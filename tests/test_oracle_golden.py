@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests.helpers import DYN_BOOL, DYN_I32, DYN_ROWS, INT_KEYS, assert_state_equal, reward_tol
+from tests.helpers import DYN_BOOL, DYN_I32, DYN_ROWS, INT_KEYS, assert_rewards_close, assert_state_equal, reward_tol
 
 
 def _env_snapshot(env):
@@ -37,7 +37,6 @@ def test_oracle_matches_reference_rollout(rollouts, oracle_table, case):
     P, MP, N, episodes, steps = [int(x) for x in rollouts[f"{case}/meta"]]
     env = orc.OraclePokerEnv(n_players=P, max_players=MP, n_games=N, starting_bbs=100, max_bbs=1000,
                              w1=.5, w2=.3, K=100, alpha=50, hand_ranks_table=oracle_table)
-    tol = reward_tol(50)
     for e in range(episodes):
         A = int(rollouts[f"{case}/A"][e])
         decks = rollouts[f"{case}/e{e}/decks"].astype(np.int32)
@@ -56,7 +55,7 @@ def test_oracle_matches_reference_rollout(rollouts, oracle_table, case):
             np.testing.assert_array_equal(obs, want["obs"], err_msg=ctx)
             np.testing.assert_array_equal(env.equities, want["equities"], err_msg=ctx)
             np.testing.assert_array_equal(dones.astype(np.uint8), rollouts[f"{case}/e{e}/steps/dones"][s], err_msg=ctx)
-            np.testing.assert_allclose(rew, rollouts[f"{case}/e{e}/steps/rewards"][s], rtol=0, atol=tol, err_msg=ctx)
+            assert_rewards_close(rew, rollouts[f"{case}/e{e}/steps/rewards"][s], 50, ctx)
 
 
 def _poked_env(methods, key, oracle_table):
@@ -103,4 +102,4 @@ def test_oracle_methods_match_reference(methods, oracle_table, ci):
     np.testing.assert_array_equal(obs, methods[f"{key}/step/post/obs"])
     np.testing.assert_array_equal(env.equities, methods[f"{key}/step/post/equities"])
     np.testing.assert_array_equal(dones.astype(np.uint8), methods[f"{key}/step/dones"])
-    np.testing.assert_allclose(rew, methods[f"{key}/step/rewards"], rtol=0, atol=reward_tol(50))
+    assert_rewards_close(rew, methods[f"{key}/step/rewards"], 50, f"{key} step")

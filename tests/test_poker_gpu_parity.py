@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import DYN_BOOL, DYN_I32, DYN_ROWS, INT_KEYS, assert_state_equal, reward_tol, to_np
+from tests.helpers import DYN_BOOL, DYN_I32, DYN_ROWS, INT_KEYS, assert_rewards_close, assert_state_equal, reward_tol, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,6 @@ def methods(golden_dir):
 def test_hip_matches_reference_rollout(rollouts, case):
     P, MP, N, episodes, steps = [int(x) for x in rollouts[f"{case}/meta"]]
     env = _gpu_env(n_players=P, max_players=MP, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
-    tol = reward_tol(50)
     for e in range(episodes):
         A = int(rollouts[f"{case}/A"][e])
         decks = torch.from_numpy(rollouts[f"{case}/e{e}/decks"].astype(np.int32))
@@ -72,7 +71,7 @@ def test_hip_matches_reference_rollout(rollouts, case):
             np.testing.assert_array_equal(to_np(obs), want["obs"], err_msg=ctx)
             np.testing.assert_array_equal(got["equities"], want["equities"], err_msg=ctx)
             np.testing.assert_array_equal(to_np(dones).astype(np.uint8), rollouts[f"{case}/e{e}/steps/dones"][s], err_msg=ctx)
-            np.testing.assert_allclose(to_np(rew), rollouts[f"{case}/e{e}/steps/rewards"][s], rtol=0, atol=tol, err_msg=ctx)
+            assert_rewards_close(rew, rollouts[f"{case}/e{e}/steps/rewards"][s], 50, ctx)
             assert info["seat_idx"] is env.idx and info["stacks"] is env.stacks
 
 
@@ -118,7 +117,7 @@ def test_hip_methods_match_reference(methods, ci):
     np.testing.assert_array_equal(got["obs"], methods[f"{key}/step/post/obs"])
     np.testing.assert_array_equal(got["equities"], methods[f"{key}/step/post/equities"])
     np.testing.assert_array_equal(to_np(dones).astype(np.uint8), methods[f"{key}/step/dones"])
-    np.testing.assert_allclose(to_np(rew), methods[f"{key}/step/rewards"], rtol=0, atol=reward_tol(50))
+    assert_rewards_close(rew, methods[f"{key}/step/rewards"], 50, f"{key} step")
 
 
 def _seeded_decks(n, seed):
@@ -143,7 +142,6 @@ def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
     env.obs_staging = variant != "no_obs_staging"
     ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
     rng = np.random.default_rng(N + P)
-    tol = reward_tol(50)
     steps = 40 if N > 10000 else 60
     for e, A in enumerate(As):
         decks = _seeded_decks(N, 20260401 + e)
@@ -164,7 +162,7 @@ def test_hip_matches_oracle_at_scale(oracle_table, N, P, As, variant):
             np.testing.assert_array_equal(got["obs"], robs, err_msg=ctx)
             np.testing.assert_array_equal(got["equities"], ref.equities, err_msg=ctx)
             np.testing.assert_array_equal(to_np(dones), rdones, err_msg=ctx)
-            np.testing.assert_allclose(to_np(rew), rrew, rtol=0, atol=tol, err_msg=ctx)
+            assert_rewards_close(rew, rrew, 50, ctx)
         assert to_np(env.is_done).mean() > 0.5
 
 
@@ -269,7 +267,7 @@ def test_fused_policy_step_matches_oracle(oracle_table, launcher):
             assert_state_equal(got, ref.snapshot(), ctx=ctx)
             np.testing.assert_array_equal(got["obs"], ref.obs, err_msg=ctx)
             if rew is not None:
-                np.testing.assert_allclose(to_np(rew), ref.rewards, rtol=0, atol=reward_tol(50), err_msg=ctx)
+                assert_rewards_close(rew, ref.rewards, 50, ctx)
     assert to_np(env.is_done).mean() > 0.5
 
 
@@ -558,7 +556,7 @@ def test_poker_reward_gpu_contracts_and_oracle(oracle_table):
     s = ref._struct()
     want = np.array([orc.lib().oracle_reward(C.byref(s), C.c_int(t), C.c_int64(int(acts[t])), C.c_int(int(actor[t]))) for t in range(N)],
                     dtype=np.float32)
-    np.testing.assert_allclose(got, want, rtol=0, atol=reward_tol(11))
+    assert_rewards_close(got, want, 11, "random reward states")
 
 
 def _allowed(corner_actions):
@@ -692,6 +690,96 @@ def test_hip_matches_oracle_at_config4_shard_size(oracle_table):
     # unless a folded player out-invested every contender, which the oracle reproduces identically)
     total = to_np(env.stacks).sum(dtype=np.int64) + to_np(env.pots).sum(dtype=np.int64)
     assert total == ref.stacks.sum(dtype=np.int64) + ref.pots.sum(dtype=np.int64)
+
+
+@pytest.mark.parametrize("N,rank,world_tables", [(65536, 0, 65536), (131072, 3, 1048576)],
+                         ids=["65536-full-lds-image-bench-kernel", "131072-slim-lds-image-config4-shard"])
+def test_chunk_kernel_matches_oracle_at_the_headline_sizes(oracle_table, N, rank, world_tables):
+    """The two kernel instantiations that carry the published numbers, held to the ORACLE directly (round 2 reached
+    them only through chunk = per-step launches = oracle): `env.rollout` in 5-step chunk launches, two lanes per table,
+      * 65,536 tables -- poker_step_kernel<STEP, POLICY, 2, 5, WOBS, MULTI=1> (full LDS image), bench.py's kernel;
+      * 131,072 tables with the global table ids of rank 3 of config 4 -- MULTI=2 (slim LDS image, > 81,920 tables);
+    device-shuffled decks (held to the oracle's shuffle definition), bench.py's rotating opponent mix, A = 10, 6, 2,
+    40 steps per episode; after EVERY chunk the complete state, both observation buffers, the last two steps' rewards
+    and done flags, and the actions are compared with OraclePokerEnv.policy_step taken one step at a time
+    (PokerGPU.py:305-329, 527-633; utils.py:108-123)."""
+    import bench
+    from oracle import oracle as orc
+    seed, t0 = 20260401, rank * N
+    assert t0 + N <= world_tables
+    kw = dict(n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
+    env = _gpu_env(seed=seed, table_id0=t0, **kw)
+    assert env.chunked_rollout and not env.chunk_four_lanes
+    ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
+    a_gpu = torch.zeros(N, dtype=torch.long, device=DEV)
+    a_ref = np.zeros(N, dtype=np.int64)
+    gstep = 0
+    for e, (A, ep_types) in enumerate(((10, 0), (6, 1), (2, 11))):          # episodes whose learner seat (e % 10) is below A
+        native, q_seat, rotation = bench.native_types_for_episode(ep_types)
+        assert q_seat < A
+        opts = {"rotation": rotation, "active_players": A, "q_agent_seat": q_seat}
+        env.reset(options=opts)
+        assert env.active_players == A
+        decks = to_np(env.decks)
+        np.testing.assert_array_equal(decks, orc.shuffle_decks(seed, t0, e, N), err_msg=f"episode {e}: device shuffle")
+        ref.reset(options=dict(opts, prefixed_decks=decks))
+        assert_state_equal(_snap(env), ref.snapshot(), ctx=f"episode {e} reset")
+        np.testing.assert_array_equal(to_np(env.obs), ref.obs)
+        for c in range(8):
+            obs, rew, dones, _, _ = env.rollout(native, a_gpu, 5, gstep)
+            prev = None
+            for i in range(5):
+                if i == 4:
+                    prev = (ref.obs.copy(), ref.rewards.copy(), ref.is_done.copy())
+                ref.policy_step(native, seed, gstep + i, a_ref, table_id0=t0)
+            gstep += 5
+            ctx = f"N={N} episode {e} (A={A}) chunk {c}"
+            np.testing.assert_array_equal(to_np(a_gpu), a_ref, err_msg=ctx + " actions")
+            got = _snap(env)
+            assert_state_equal(got, ref.snapshot(), ctx=ctx)
+            np.testing.assert_array_equal(got["obs"], ref.obs, err_msg=ctx + " obs")
+            np.testing.assert_array_equal(got["equities"], ref.equities, err_msg=ctx + " equities")
+            np.testing.assert_array_equal(to_np(dones), ref.is_done.astype(bool), err_msg=ctx + " dones")
+            assert_rewards_close(rew, ref.rewards, 50, ctx)
+            for name in ("prev_stacks", "prev_invested"):
+                np.testing.assert_array_equal(to_np(getattr(env, name)), getattr(ref, name), err_msg=f"{ctx} {name}")
+            # what the chunk's FOURTH step stored (the other reward / done set of the ping-pong pair)
+            assert_rewards_close(env._rewards[env._pp], prev[1], 50, ctx + " (step 4 of 5)")
+            np.testing.assert_array_equal(to_np(env._done_bufs[1 - env._pp]).astype(np.uint8), prev[2], err_msg=ctx + " dones of step 4")
+        assert 0.3 < to_np(env.is_done).mean() <= 1.0
+    # exact-rounding census: the oracle rounds libm's double tanh, the kernel its own (tanh_rn); they may differ in
+    # ~1e-8 of the arguments, i.e. essentially never in one chunk
+    assert (to_np(rew) != ref.rewards).mean() < 1e-4
+
+
+def test_bench_gpu_leg_and_cpu_baseline_play_the_same_episodes():
+    """bench.py's two legs against each other (they "play the same games" without comparing a number):
+    8 episodes of the GPU leg (EpisodeLoop: native rollout_until + the lag-1 stop rule, device shuffle) and of the
+    cpu_baseline loop (oracle: shuffle + reset + policy + step, the same rule one check late) must end on the same step,
+    with the same number of finished tables and the same sum of the last step's rewards."""
+    import bench
+    from pulselib_amd.stoprule import LaggedDoneCount
+    N, episodes = 65536, 8
+    args = bench.parse_args(["--tables", str(N)])
+    want = bench.cpu_episode_trace(N, episodes, lag=1, max_episode_steps=args.max_episode_steps, threads=16)
+    dev = torch.device(DEV)
+    env = _gpu_env(n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=bench.SEED)
+    rule = LaggedDoneCount(dev, N, bench.TERMINATION_THRESHOLD, lag=1)
+    got = []
+
+    def at_end(loop):
+        r = loop.env._rewards[1 - loop.env._pp]                                  # the set the last step wrote
+        got.append((loop.steps_in_episode, int(loop.env.is_done.sum()), float(r.double().sum())))
+
+    actions = torch.zeros(N, dtype=torch.long, device=dev)
+    loop = bench.EpisodeLoop(env, rule, actions, args.max_episode_steps, on_episode_end=at_end)
+    while len(got) < episodes:
+        loop.run_steps(5)
+    for e, (g, w) in enumerate(zip(got, want)):
+        assert g[0] == w["steps"] and g[1] == w["done"], f"episode {e}: GPU {g} oracle {w}"
+        assert abs(g[2] - w["reward_sum"]) <= 1e-5 * N, f"episode {e}: reward sums {g[2]} vs {w['reward_sum']}"
+    assert len({w["steps"] for w in want}) > 1 or want[0]["steps"] < args.max_episode_steps, "the rule never fired in 8 episodes"
+    rule.close()
 
 
 def test_native_stop_rule_fixed_lag_counts_and_drains():
