@@ -262,10 +262,15 @@ int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_
  * stacks[t][q_seat] - initial_q_stacks[t] is added to acc[position][bucket][4] = {hands, wins, sum delta, sum delta^2}
  * (device int64[16*5*4], zeroed by the caller when a new aggregation starts); position = (q_seat - button[t]) mod
  * active_players, bucket = clamp(stages[t], 0, 4).  No host sync; BB/100, win rates by street / position and the
- * confidence bound follow from the sums on the host (pulselib_amd/utils/performance.py). */
+ * confidence bound follow from the sums on the host (pulselib_amd/utils/performance.py).
+ * The ordered hand log (optional; both NULL or both set): finish_step[t] = step_index and hand_delta[t] = the delta for
+ * every table accounted in this call (device int32[n] each; the caller fills finish_step with -1 when an episode
+ * starts).  Sorting the finished tables by (finish_step, t) gives the hands in the order the reference's per-step
+ * boolean pulls append them -- what its rolling-window average runs over (utils/performance.py:128-135). */
 int pulse_poker_hand_metrics(const uint8_t* dones, const uint8_t* terminated_before, const int32_t* stacks, int32_t n_players,
                              const int32_t* initial_q_stacks, const int32_t* stages, const int32_t* button, int32_t q_seat,
-                             int32_t active_players, int32_t n, int64_t* acc, void* stream);
+                             int32_t active_players, int32_t n, int64_t* acc, int32_t step_index, int32_t* finish_step,
+                             int32_t* hand_delta, void* stream);
 
 /* ---- Blackjack (environments/blackjack/blackjack.py) ------------------------------------------ */
 typedef struct PulseBlackjackView {

@@ -115,7 +115,7 @@ SYMBOLS = {
     "pulse_poker_ablate": (C.c_int, [_P, _U32, _P, _P, _U64, _U64, _P]),
     "pulse_calib_stream": (C.c_int, [_P, _U64, _I32, _P]),
     "pulse_poker_stats": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
-    "pulse_poker_hand_metrics": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "pulse_poker_hand_metrics": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _P, _P, _P]),
     "pulse_blackjack_reset": (C.c_int, [_P, _P, _P, _U64, _U64, _P]),
     "pulse_blackjack_step": (C.c_int, [_P, _P, _P]),
     "pulse_tfe_reset": (C.c_int, [_P, _P, _I32, _I32, _U64, _U64, _P]),

@@ -281,13 +281,17 @@ __global__ __launch_bounds__(kBlock) void poker_hand_metrics_kernel(const uint8_
                                                                    const int32_t* __restrict__ stacks, int n_players,
                                                                    const int32_t* __restrict__ initial_q_stacks, const int32_t* __restrict__ stages,
                                                                    const int32_t* __restrict__ button, int q_seat, int active_players, int n,
-                                                                   unsigned long long* __restrict__ acc) {
+                                                                   unsigned long long* __restrict__ acc, int step_index,
+                                                                   int32_t* __restrict__ finish_step, int32_t* __restrict__ hand_delta) {
     __shared__ unsigned long long h[PULSE_MAX_SEATS * 5 * 4];
     for (int i = threadIdx.x; i < PULSE_MAX_SEATS * 5 * 4; i += kBlock) h[i] = 0ull;
     __syncthreads();
     for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
         if (!dones[t] || (terminated_before && terminated_before[t])) continue;
         const long long delta = (long long)stacks[(size_t)t * n_players + q_seat] - (long long)initial_q_stacks[t];
+        // the ordered hand log (the rolling window of utils/performance.py:128-135 needs the hands in the order the
+        // reference's per-step boolean pulls produce: by step, then by table): two words per table, written once
+        if (finish_step) { finish_step[t] = step_index; hand_delta[t] = (int32_t)delta; }
         const int pos = pymod(q_seat - button[t], active_players);
         const int bucket = min(max(stages[t], 0), 4);                         // 0..3 the street, 4 = showdown (stage codes 4 and 5)
         unsigned long long* cell = h + ((pos & (PULSE_MAX_SEATS - 1)) * 5 + bucket) * 4;
@@ -416,15 +420,17 @@ int pulse_poker_stats(const uint8_t* is_done, const float* rewards, const uint8_
 
 int pulse_poker_hand_metrics(const uint8_t* dones, const uint8_t* terminated_before, const int32_t* stacks, int32_t n_players,
                              const int32_t* initial_q_stacks, const int32_t* stages, const int32_t* button, int32_t q_seat,
-                             int32_t active_players, int32_t n, int64_t* acc, void* stream) {
-    if (!dones || !stacks || !initial_q_stacks || !stages || !button || !acc || n < 0)
-        return pulse::fail(PULSE_EINVAL, "pulse_poker_hand_metrics: null argument");
+                             int32_t active_players, int32_t n, int64_t* acc, int32_t step_index, int32_t* finish_step,
+                             int32_t* hand_delta, void* stream) {
+    if (!dones || !stacks || !initial_q_stacks || !stages || !button || !acc || n < 0 || (finish_step != nullptr) != (hand_delta != nullptr))
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_hand_metrics: null argument (finish_step and hand_delta come together)");
     if (n_players < 2 || n_players > PULSE_MAX_SEATS || active_players < 2 || active_players > n_players || q_seat < 0 || q_seat >= n_players)
         return pulse::fail(PULSE_EINVAL, "pulse_poker_hand_metrics: need 2 <= active_players <= n_players <= 16 and 0 <= q_seat < n_players");
     if (n == 0) return 0;
     const int grid = min(256, (n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(poker_hand_metrics_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, dones, terminated_before, stacks,
-                       n_players, initial_q_stacks, stages, button, q_seat, active_players, n, reinterpret_cast<unsigned long long*>(acc));
+                       n_players, initial_q_stacks, stages, button, q_seat, active_players, n, reinterpret_cast<unsigned long long*>(acc),
+                       step_index, finish_step, hand_delta);
     return pulse::finish_launch("pulse_poker_hand_metrics");
 }
 

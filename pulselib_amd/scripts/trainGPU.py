@@ -92,7 +92,7 @@ def train_agent(env, agents, agent_types, episodes, n_games, device, results_dir
 
 def train_agent_fused(env, agents, agent_types, episodes, n_games, device, results_dir=None, config=None, plotter=None,
                       benchmarker=None, max_episode_steps=None, reduce_stats=True, stop_rule="lagged", host_seed=0,
-                      step_hook=None, learner="native", hand_metrics=None):
+                      step_hook=None, learner="native", hand_metrics=None, prefixed_decks=None):
     """train_agent with nothing in the step waiting on the host: the loop contract above (rotation, masks evaluated
     before `terminated |= dones`, stop cadence, step accounting) on four launches-groups per step --
       learner's actions (pulse_qnet_act, masked by seat) -> scripted opponents + env step (pulse_poker_policy_step) ->
@@ -140,7 +140,10 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         _, rotated_types, q_seat, rotations = get_rotated_agents(agents, agent_types, episode_idx=episode, q_agent_idx=q_agent_idx)
         native_seats = native_types(rotated_types)               # the learner's seat is EXTERNAL: its action is taken as given
         A = host_rng.randint(2, env.n_players)
-        state, info = env.reset(options={"rotation": rotations, "active_players": int(A), "q_agent_seat": q_seat})
+        options = {"rotation": rotations, "active_players": int(A), "q_agent_seat": q_seat}
+        if prefixed_decks is not None:                           # USE_PREFIXED_DECKS: episode -> int32[n_games, 52] (trainGPU_performance.py:52)
+            options["prefixed_decks"] = prefixed_decks(episode)
+        state, info = env.reset(options=options)
         initial_stacks = info["stacks"][:, q_seat].clone()
         terminated.zero_()
         episode_reward.zero_()
@@ -217,44 +220,64 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
 
 
 def main(argv=None):
-    """python -m pulselib_amd.scripts.trainGPU [--tables N] [--episodes E] [--results DIR]: the reference's
-    scripts/Poker/trainGPU.py:148-214 on the fused loop -- PokerQNetwork + the config's opponents, run summary written
-    as results/PokerGPU/runs/run_N.yaml (utils/benchmarking.py) and the final weights as poker_qnet_final.pth."""
+    """python -m pulselib_amd.scripts.trainGPU [--config PATH] [--tables N] [--episodes E] [--results DIR]: the reference's
+    entry point (scripts/Poker/trainGPU.py:148-214) on the fused loop.  The configuration is the reference's own schema
+    (config/pokerGPU.yaml, flat keys; utils/config.py) -- its file can be passed as it is -- plus the optional engine keys
+    N_GPUS / SEED / USE_PREFIXED_DECKS / MAX_EPISODE_STEPS.  Writes the run summary results/PokerGPU/runs/run_N.yaml
+    (utils/benchmarking.py: YamlBenchmarker, the reference writer's keys and numbering) and poker_qnet_final.pth."""
     import argparse
-
-    import yaml
+    import os
 
     from ..environments.Poker import PokerGPU, PokerQNetwork, load_gpu_agents
+    from ..sharding import shard_tables
     from ..utils.benchmarking import YamlBenchmarker, result_folder_for
+    from ..utils.config import get_config_file, poker_gpu_arguments
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tables", type=int, default=None)
-    ap.add_argument("--episodes", type=int, default=None)
+    ap.add_argument("--config", default="pokerGPU.yaml", help="file name under pulselib_amd/config/, or a path (e.g. the reference's config/pokerGPU.yaml)")
+    ap.add_argument("--tables", type=int, default=None, help="override N_GAMES")
+    ap.add_argument("--episodes", type=int, default=None, help="override EPISODES")
     ap.add_argument("--results", type=Path, default=Path.cwd() / "results")
     args = ap.parse_args(argv)
-    cfg = yaml.safe_load((Path(__file__).resolve().parent.parent / "config" / "pokerGPU.yaml").read_text())
-    env_cfg, rew, learner = cfg["env"], cfg["reward"], cfg["learner"]
+    config = get_config_file(args.config)
+    if config is None:
+        raise FileNotFoundError(f"no configuration file {args.config!r}")
+    if args.tables is not None:
+        config["N_GAMES"] = int(args.tables)
+    if args.episodes is not None:
+        config["EPISODES"] = int(args.episodes)
+    a = poker_gpu_arguments(config)
+    engine = a["engine"]
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                           # launched as one process per GPU (torchrun): N_GPUS must agree
+        import torch.distributed as dist
+        if int(engine["N_GPUS"]) != world:
+            raise ValueError(f"N_GPUS is {engine['N_GPUS']} but the job has {world} ranks")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    elif int(engine["N_GPUS"]) != 1:
+        raise ValueError(f"N_GPUS is {engine['N_GPUS']}: start one process per GPU (python -m torch.distributed.run --nproc-per-node {engine['N_GPUS']} -m pulselib_amd.scripts.trainGPU ...)")
     device = torch.device("cuda", torch.cuda.current_device())
-    n_games = int(args.tables or env_cfg["tables"])
-    episodes = int(args.episodes or cfg["run"]["episodes"])
-    agents, types = load_gpu_agents(device, env_cfg["opponents"], list(cfg["opponent_mix"]), env_cfg["starting_stack_bb"], env_cfg["actions"])
-    results_dir = result_folder_for(env_cfg["id"], args.results)
-    q_net = PokerQNetwork(weights_path=results_dir / "poker_qnet_final.pth", device=device, gamma=learner["gamma"],
-                          update_freq=int(learner["target_update_every"]), state_dim=env_cfg["observation_size"],
-                          action_dim=env_cfg["actions"], learning_rate=float(learner["learning_rate"]),
-                          weight_decay=float(learner["weight_decay"]), seed=env_cfg.get("seed", 0))
-    agents.insert(0, q_net)
+    n_local, table_id0 = shard_tables(int(a["env"]["n_games"]), world, rank)
+    agents, types = load_gpu_agents(device, *a["agents_args"])                                    # trainGPU.py:156-162
+    results_dir = result_folder_for(a["env_id"], args.results)
+    q_net = PokerQNetwork(weights_path=results_dir / "poker_qnet_final.pth", device=device, seed=int(engine["SEED"]), **a["q_network"])
+    agents.insert(0, q_net)                                                                       # :174-175
     types.insert(0, PokerAgentType.QLEARNING)
-    env = PokerGPU(device=device, agents=agents, n_players=env_cfg["opponents"] + 1, n_games=n_games,
-                   starting_bbs=env_cfg["starting_stack_bb"], w1=rew["w1"], w2=rew["w2"], K=rew["K"], alpha=rew["alpha"],
-                   seed=env_cfg.get("seed", 0))
-    run_config = {"ENV_ID": env_cfg["id"], "N_GAMES": n_games, "EPISODES": episodes, "NUM_PLAYERS": env_cfg["opponents"],
-                  "AGENTS": list(cfg["opponent_mix"]), "GAMMA": learner["gamma"], "LEARNING_RATE": learner["learning_rate"],
-                  "WEIGHT_DECAY": learner["weight_decay"], "UPDATE_FREQ": learner["target_update_every"], **rew}
-    out = train_agent_fused(env, agents, types, episodes, n_games, device, results_dir=results_dir, config=run_config,
-                            benchmarker=YamlBenchmarker(results_dir_resolver=lambda env_name: results_dir),
-                            max_episode_steps=env_cfg.get("max_episode_steps"))
-    torch.save(q_net.network.state_dict(), results_dir / "poker_qnet_final.pth")          # trainGPU.py:118
-    print({k: out[k] for k in ("total_steps", "total_training_seconds", "sps")})
+    env = PokerGPU(device=device, agents=agents, seed=int(engine["SEED"]), table_id0=table_id0, **dict(a["env"], n_games=n_local))   # :177-188
+    benchmarker = YamlBenchmarker.from_config(a["benchmarking"])                                  # :153
+    benchmarker.results_dir_resolver = lambda env_name: results_dir
+    if rank != 0:
+        benchmarker.enabled = False
+    prefixed = None
+    if engine["USE_PREFIXED_DECKS"]:
+        from ..utils.performance import build_prefixed_deck_batch
+        prefixed = lambda episode: build_prefixed_deck_batch(n_games=n_local, seed=int(engine["SEED"]) + episode, device=device)   # noqa: E731
+    out = train_agent_fused(env, agents, types, int(a["train"]["episodes"]), n_local, device, results_dir=results_dir, config=config,
+                            benchmarker=benchmarker, max_episode_steps=engine["MAX_EPISODE_STEPS"], prefixed_decks=prefixed)
+    if rank == 0:
+        torch.save(q_net.network.state_dict(), results_dir / "poker_qnet_final.pth")             # trainGPU.py:118
+        print({k: out[k] for k in ("total_steps", "total_training_seconds", "sps")})
     return out
 
 

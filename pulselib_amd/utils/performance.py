@@ -5,8 +5,11 @@ The reference's benchmark trainer (scripts/Poker/trainGPU_performance.py:198-206
 sync each -- and keeps per-hand lists that utils/performance.py reduces at the end.  Every metric it reports except
 the rolling window is a function of per-group sums, so `HandMetrics` keeps exactly those on the device
 (pulse_poker_hand_metrics: hands, wins, sum delta, sum delta^2 per (button-relative position, street bucket), exact
-int64) and folds them into host totals per episode, keyed by the episode's player count.  Metric names and formulas
-follow utils/performance.py (cited per function); values are plain floats."""
+int64) and folds them into host totals per episode, keyed by the episode's player count.  The rolling window
+(`rolling_window_size`, utils/performance.py:128-135) needs the hands IN ORDER: the same launch notes, per table, the
+step it finished at and its delta; at the episode's end one sort by (step, table) restores the order of the reference's
+per-step boolean pulls -- still no sync inside the episode.  Metric names and formulas follow utils/performance.py
+(cited per function); values are plain floats."""
 from __future__ import annotations
 
 import math
@@ -42,10 +45,51 @@ def lcb95_bb_per_100(count: int, total: float, total_sq: float) -> float:
     return 100.0 * (mean - CONFIDENCE_Z_95 * math.sqrt(var) / math.sqrt(count))
 
 
-class HandMetrics:
-    """Device accumulators for one run; `begin_episode` / `update` per step / `end_episode`, then `summary()`."""
+def build_prefixed_deck_batch(*, n_games: int, seed: int, device) -> torch.Tensor:
+    """One deterministic shuffled deck per game from a CPU generator seeded `seed` (utils/performance.py:62-67;
+    scripts/Poker/trainGPU_performance.py:52 uses seed = 20260401 + episode)."""
+    generator = torch.Generator(device="cpu")
+    generator.manual_seed(int(seed))
+    shuffled = torch.rand((n_games, 52), generator=generator).argsort(dim=1) + 1
+    return shuffled.to(device=device, dtype=torch.int32)
 
-    def __init__(self, device, n_tables: int):
+
+def calculate_rolling_window_averages(hand_bb_deltas, *, window_size: int) -> torch.Tensor:
+    """Rolling mean big-blind delta over completed hands, in the order given (utils/performance.py:128-135: the fp32
+    `unfold(0, W, 1).mean(dim=1)` of the flattened per-hand list).  `hand_bb_deltas`: a tensor or a list of tensors (one
+    per step / per episode, in order).  Returns a float32 tensor of len(deltas) - W + 1 averages (empty if fewer hands)."""
+    batches = hand_bb_deltas if isinstance(hand_bb_deltas, (list, tuple)) else [hand_bb_deltas]
+    batches = [torch.as_tensor(b) for b in batches if b is not None]
+    if not batches:
+        return torch.empty(0, dtype=torch.float32)
+    deltas = torch.cat([b.reshape(-1).to(device=batches[0].device, dtype=torch.float32) for b in batches], dim=0)
+    if window_size <= 0 or deltas.numel() < window_size:
+        return torch.empty(0, dtype=torch.float32, device=deltas.device)
+    return deltas.unfold(0, window_size, 1).mean(dim=1)
+
+
+def rolling_bb_window_summary(hand_bb_deltas, window_size: int) -> dict:
+    """The `rolling_bb_window` block of calculate_final_performance_metrics (utils/performance.py:452-457)."""
+    avg = calculate_rolling_window_averages(hand_bb_deltas, window_size=window_size)
+    n = int(avg.numel())
+    return {"window_size": int(window_size), "num_windows": n, "last_average": float(avg[-1]) if n else 0.0,
+            "best_average": float(avg.max()) if n else 0.0, "values": avg.detach().cpu().numpy()}
+
+
+class HandMetrics:
+    """Device accumulators for one run; `begin_episode` / `update` per step / `end_episode`, then `summary()`.
+    `rolling_window_size` > 0 also keeps the ordered per-hand deltas (8 bytes per table on the device, one sort per
+    episode) and adds the `rolling_bb_window` block to the summary."""
+
+    def __init__(self, device, n_tables: int, rolling_window_size: int = 0):
+        self.rolling_window_size = int(rolling_window_size)
+        self.hand_deltas = []                # per episode: float32 tensor of the finished hands' deltas, in the reference's order
+        self._step = 0
+        self._finish = self._delta = self._table_ids = None
+        if self.rolling_window_size > 0:
+            self._finish = torch.full((int(n_tables),), -1, dtype=torch.int32, device=device)
+            self._delta = torch.zeros(int(n_tables), dtype=torch.int32, device=device)
+            self._table_ids = torch.arange(int(n_tables), dtype=torch.int64, device=device)
         self.device, self.n = device, int(n_tables)
         self.acc = torch.zeros(MAX_SEATS * BUCKETS * 4, dtype=torch.int64, device=device)
         self.initial = torch.zeros(self.n, dtype=torch.int32, device=device)
@@ -59,6 +103,9 @@ class HandMetrics:
         self.q_seat, self.active_players, self.mix_id = int(q_seat), int(env.active_players), int(mix_id)
         self.initial.copy_(env.stacks[:, self.q_seat])
         self.acc.zero_()
+        self._step = 0
+        if self._finish is not None:
+            self._finish.fill_(-1)
 
     def update(self, env, dones: torch.Tensor, terminated_before: torch.Tensor | None) -> None:
         """after env.step and BEFORE `terminated |= dones`: account the hands that finished in this step (:192-206)."""
@@ -68,7 +115,9 @@ class HandMetrics:
         _native.check(self._lib.pulse_poker_hand_metrics(
             d.data_ptr(), None if t is None else t.data_ptr(), env.stacks.data_ptr(), env.n_players, self.initial.data_ptr(),
             env.stages.data_ptr(), env.button.data_ptr(), self.q_seat, self.active_players, self.n, self.acc.data_ptr(),
+            self._step, None if self._finish is None else self._finish.data_ptr(), None if self._delta is None else self._delta.data_ptr(),
             torch.cuda.current_stream(self.device).cuda_stream), "pulse_poker_hand_metrics")
+        self._step += 1
 
     def end_episode(self) -> dict:
         """One read-back per episode (at the point where the trainer reads its episode sums anyway); returns the
@@ -77,11 +126,19 @@ class HandMetrics:
         tot = self.totals.setdefault((self.active_players, self.mix_id), np.zeros((MAX_SEATS, BUCKETS, 4), dtype=np.int64))
         tot += a
         hands, wins, total = int(a[..., 0].sum()), int(a[..., 1].sum()), float(a[..., 2].sum())
+        if self._finish is not None and hands:
+            # the hands in the reference's order: by the step they finished at, then by table (trainGPU_performance.py:198-206)
+            key = torch.where(self._finish >= 0, self._finish.to(torch.int64) * self.n + self._table_ids, torch.iinfo(torch.int64).max)
+            order = torch.argsort(key)[:hands]
+            self.hand_deltas.append(self._delta[order].to(torch.float32))
         return {"mean_bb_delta": total / hands if hands else 0.0, "hand_win_rate": wins / hands if hands else 0.0,
                 "hands_completed": hands, "field_bb_per_100": bb_per_100(hands, total)}
 
     def summary(self) -> dict:
-        return summarize_totals(self.totals)
+        out = summarize_totals(self.totals)
+        if self.rolling_window_size > 0:
+            out["rolling_bb_window"] = rolling_bb_window_summary(self.hand_deltas, self.rolling_window_size)
+        return out
 
 
 def accumulate_hands(deltas, stages, positions, player_counts, mix_ids=None) -> dict:

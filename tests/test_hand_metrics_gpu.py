@@ -16,7 +16,7 @@ def test_hand_metrics_match_per_hand_lists():
     dev = torch.device(DEV)
     N, P = 4096, 10
     env = PokerGPU(device=dev, agents=[], n_players=P, max_players=P, n_games=N, seed=9)
-    hm = HandMetrics(dev, N)
+    hm = HandMetrics(dev, N, rolling_window_size=50)
     rng = np.random.default_rng(4)
     deltas, stages, positions, counts, episode_rows = [], [], [], [], []
     for ep, (A, q_seat) in enumerate(((6, 2), (10, 7), (2, 1), (6, 0))):
@@ -75,5 +75,14 @@ def test_hand_metrics_match_per_hand_lists():
         assert abs(s["slices"]["player_count"][f"players_{a}"] - 100 * d[pc == a].mean()) < 1e-7
     for b in np.unique(bucket):
         assert abs(s["slices"]["street_depth"][names[b]] - 100 * d[bucket == b].mean()) < 1e-7
+    # rolling window (:128-135, :452-457): the device's ordered hand log = the order of the reference's boolean pulls, so
+    # the fp32 unfold().mean() over it reproduces the reference's list value for value
+    assert len(hm.hand_deltas) == 4
+    np.testing.assert_array_equal(torch.cat(hm.hand_deltas).cpu().numpy(), d.astype(np.float32))
+    want_roll = torch.from_numpy(d.astype(np.float32)).unfold(0, 50, 1).mean(dim=1).numpy()
+    roll = s["rolling_bb_window"]
+    assert roll["window_size"] == 50 and roll["num_windows"] == d.size - 49
+    np.testing.assert_allclose(roll["values"], want_roll, rtol=1e-6, atol=1e-6)
+    assert abs(roll["last_average"] - want_roll[-1]) < 1e-5 and abs(roll["best_average"] - want_roll.max()) < 1e-5
     allv = [v for fam in s["slices"].values() for v in fam.values()]
     assert s["worst_slice"]["bb_per_100"] == min(allv)                             # :321-349

@@ -131,3 +131,35 @@ def test_hand_metric_summaries_equal_utils_performance(golden_dir):
         d = fx["delta"][m]
         got = [d.mean(), (d > 0).mean(), d.size, 100 * d.mean()] if d.size else [0, 0, 0, 0]
         assert all(rel(g, w) for g, w in zip(got, want)), ep
+
+
+def test_rolling_window_averages_equal_utils_performance(golden_dir):
+    """f2, the last output of utils/performance.py HandMetrics did not reproduce: the rolling-window mean
+    BB delta (utils/performance.py:128-135, reported at :452-457), on the reference's own per-hand order; fixture values are
+    the reference's (make_golden.py: make_performance, window 50)."""
+    import torch
+    from pulselib_amd.utils.performance import calculate_rolling_window_averages, rolling_bb_window_summary
+    fx = np.load(golden_dir / "performance.npz")
+    deltas = torch.from_numpy(fx["delta"].astype(np.float32))
+    W = int(fx["final/rolling/window_size"])
+    per_episode = [deltas[torch.from_numpy(fx["episode"] == e)] for e in np.unique(fx["episode"])]     # a list of batches, as the trainer keeps them
+    for form in (deltas, per_episode):
+        got = rolling_bb_window_summary(form, W)
+        assert got["num_windows"] == int(fx["final/rolling/num_windows"]) == deltas.numel() - W + 1
+        np.testing.assert_allclose(got["values"], fx["final/rolling/values"], rtol=1e-6, atol=1e-6)
+        assert abs(got["last_average"] - float(fx["final/rolling/last_average"])) < 1e-5
+        assert abs(got["best_average"] - float(fx["final/rolling/best_average"])) < 1e-5
+    assert calculate_rolling_window_averages(deltas[:W - 1], window_size=W).numel() == 0          # fewer hands than the window: []
+    assert calculate_rolling_window_averages(deltas, window_size=0).numel() == 0
+
+
+def test_prefixed_deck_batch_is_the_reference_construction(golden_dir):
+    """utils/performance.py:62-67 (seed 20260401 + episode, trainGPU_performance.py:52): the decks of the recorded
+    roll-outs were built by the generator script with the same construction from the same torch generator."""
+    import torch
+    from pulselib_amd.utils.performance import build_prefixed_deck_batch
+    d = build_prefixed_deck_batch(n_games=64, seed=20260401, device=torch.device("cpu"))
+    assert d.dtype == torch.int32 and tuple(d.shape) == (64, 52)
+    assert bool((d.sort(dim=1).values == torch.arange(1, 53, dtype=torch.int32)).all())
+    g = torch.Generator(device="cpu"); g.manual_seed(20260401)
+    assert torch.equal(d, (torch.rand((64, 52), generator=g).argsort(dim=1) + 1).to(torch.int32))
