@@ -63,6 +63,7 @@ enum {
 #define PULSE_VIEW_NO_OBS_STAGING 0x1  /* store the observation column by column instead of LDS-staged 16-byte bursts  */
 #define PULSE_VIEW_NO_CHUNK       0x2  /* pulse_poker_rollout: one launch per step instead of one launch per chunk     */
 #define PULSE_VIEW_FOUR_LANES     0x4  /* chunk launches: four lanes per table also where two are the default (<= 10 seats) */
+#define PULSE_VIEW_NO_PAIRS       0x8  /* pulse_poker_rollout_until: one check interval per launch instead of two (lag 1)  */
 typedef struct PulsePokerView {
     int32_t n_games, n_players, active_players, max_players;   /* n_games <= 2^24 per view (shard larger batches) */
     int32_t obs_size, hand_ranks_len;
@@ -186,7 +187,13 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
  * (pulse_stoprule_decide), until the rule ends the episode or max_steps steps have run -- no interpreter between the
  * chunks.  *steps_done: steps executed (the caller's views / reward buffers have swapped roles if it is odd);
  * *over: the rule fired.  timer + time_every > 0: every time_every-th chunk opens a HIP-event bracket over the next
- * eight chunks of the call (an event pair around every single launch costs the stream a fifth of the launch). */
+ * eight chunks of the call (an event pair around every single launch costs the stream a fifth of the launch).
+ * With a lag-1 rule (and unless the view says PULSE_VIEW_NO_PAIRS) ONE launch runs up to TWO check intervals: under
+ * the fixed-lag rule a chunk runs iff the count two check points back did not end the episode, and both counts a
+ * two-chunk launch needs belong to launches that have completed when it starts -- its first workgroup sums and
+ * publishes them, the host answers with the launch's verdict word in pinned memory, and every wavefront reads the
+ * relayed word before its first store (the launch then runs two chunks, one, or none).  Episodes come out step for
+ * step as with one chunk per launch; the state is loaded and written back half as often. */
 int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                               uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
                               float* rewards_even, float* rewards_odd, int32_t chunk_steps, int32_t max_steps, void* timer,

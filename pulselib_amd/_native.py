@@ -24,7 +24,7 @@ PH_FOLDWIN, PH_SHOWDOWN, PH_CLEARDONE, PH_REWARD, PH_OBS = 0x010, 0x020, 0x040, 
 PH_STEP = 0x1FF
 
 # PulsePokerView.flags: kernel variants selectable per view (include/pulse_env.h)
-VIEW_NO_OBS_STAGING, VIEW_NO_CHUNK, VIEW_FOUR_LANES = 0x1, 0x2, 0x4
+VIEW_NO_OBS_STAGING, VIEW_NO_CHUNK, VIEW_FOUR_LANES, VIEW_NO_PAIRS = 0x1, 0x2, 0x4, 0x8
 
 AGENT_EXTERNAL, AGENT_RANDOM, AGENT_HEURISTIC_HANDS, AGENT_TIGHT_AGGRESSIVE, AGENT_LOOSE_PASSIVE, AGENT_SMALL_BALL = range(6)
 

@@ -45,12 +45,25 @@ struct PolicyArgs {
     uint32_t* wave_done;                   // nullptr, or one word per wavefront of the launch: tables done after the last step
     // the PREVIOUS check point's wavefront counts, summed and published to the host by workgroup 0 of this launch, before its own tables
     const uint32_t* carry_partials; int carry_n; long long* carry_host; long long carry_seq;
+    // paired launches (pulse_internal.h: StopRulePair): a second carried check point, the counts after the launch's first
+    // chunk, and the verdict word {launch id << 8 | skip_all | stop_mid << 1 | error << 7} the host answers the carries with
+    const uint32_t* carry2_partials; int carry2_n; long long* carry2_host; long long carry2_seq;
+    uint32_t* wave_done_mid; int mid_step;
+    const long long* verdict_host; long long* verdict_dev; long long verdict_id;
 };
+constexpr int kVerdictStride = 16;                          // long longs between the 64 copies of a relayed verdict word (one 128-byte line each)
+constexpr long long kVerdictSpinTicks = 300000000ll;      // 3 s of the 100 MHz wall clock: a launch never waits for a dead host for ever
 struct ChunkArgs {                         // MULTI only: the odd steps' output buffers and the number of steps
     float* obs_odd;
     float* rewards_odd;
     int n_steps;
 };
+
+// The kernel-argument segment as the kernel below receives it.  Values needed once inside (or after) the long step loop
+// are re-read from it through a constant-address-space pointer (scalar loads) instead of being kept in scalar
+// registers across the loop, where they were spilled to vector lanes.
+struct StepKernargs { PulsePokerView v; int64_t* actions; const int32_t* actor_idx_in; float* rewards; PolicyArgs pa; ChunkArgs ca; };
+typedef const __attribute__((address_space(4))) StepKernargs* StepKernargsPtr;
 
 // In-kernel timeline (diagnostic build only, -DPULSE_STAMPS=1 -> libpulse_hip_stamps.so; no stamp executes
 // in the product): lane 0 of every wavefront stores s_memtime at phase boundaries into a buffer of its own.
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
         // the grid fills the chip exactly, so that workgroup only got a slot when the first one retired and the host
         // learned the count ~35 us later than it could -- too late to keep the queue fed at an episode boundary.)
         sum_and_publish<kStepBlock>(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
+        if (pa.carry2_n > 0) { __syncthreads(); sum_and_publish<kStepBlock>(pa.carry2_partials, pa.carry2_n, nullptr, pa.carry2_host, pa.carry2_seq); }
     }
     const int gt = blockIdx.x * kStepBlock + threadIdx.x;
     const int t = gt / LPT;
@@ -252,6 +266,45 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // Paired launch: the host answers the carried counts with this launch's verdict word; thread 0 of the launch relays
+    // it from pinned memory into device memory (one poller on PCIe), everybody reads it there before the first step --
+    // nothing has been stored yet: if the episode turns out to have ended before this launch, the launch leaves no
+    // trace.  (The answer takes the host ~5 us from the launch's start; the load burst above takes the wavefronts longer.)
+    bool stop_mid = false;                 // the previous launch's final count ends the episode after this launch's first chunk
+    if (MULTI && pa.verdict_dev) {
+        // All accesses to the relayed word are RELAXED system-scope atomics: they bypass the (per-XCD, mutually
+        // non-coherent) L2s without the cache-wide invalidate / write-back an acquire / release at agent scope costs --
+        // 2,048 wavefronts invalidating their L2 in a spin loop tripled the launch time.  The word carries its own
+        // launch id, so no other data needs ordering with it.  It is replicated over 64 cache lines (one store
+        // instruction of the relaying wavefront); wavefront w polls copy w mod 64.
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            int flags = 0;
+            if (threadIdx.x == 0) {
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    const long long w = __hip_atomic_load(pa.verdict_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((w >> 8) == pa.verdict_id) { flags = (int)(w & 0xFF); break; }
+                    if (wall_clock64() - t0 > kVerdictSpinTicks) { flags = 0x81; break; }     // error: treat as "over", run nothing
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            flags = __builtin_amdgcn_readfirstlane(flags);
+            __hip_atomic_store(pa.verdict_dev + (threadIdx.x & 63) * kVerdictStride, (pa.verdict_id << 8) | (long long)flags, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const long long* mine = pa.verdict_dev + (((blockIdx.x * kStepBlock + threadIdx.x) >> 6) & 63) * kVerdictStride;
+        const long long t0 = wall_clock64();
+        long long w;
+        for (;;) {
+            w = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((w >> 8) == pa.verdict_id) break;
+            if (wall_clock64() - t0 > 2 * kVerdictSpinTicks) { w = 0x81; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        const int flags = __builtin_amdgcn_readfirstlane((int)w);
+        if (flags & 1) return;
+        stop_mid = (flags & 2) != 0;
+    }
     // hole cards of one seat, as every lane of the table may ask: what SEAT_PICK(h0/h1, seat) yields (seat in 0..15)
     auto hand_of_seat = [&](int seat) -> int2 {
         if (seat < P_) return *reinterpret_cast<const int2*>(l_hands + (q * P_ + seat) * 2);
@@ -319,12 +372,13 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
     // the caller's action word was loaded with the state; pin its arrival to the prologue's waits: left pending, its one
     // use after the loop (the final store of the action) became an s_waitcnt vmcnt(0) behind every store of the last step
     if (MULTI) asm volatile("" : "+v"(act64));
-    const int n_steps = MULTI ? ca.n_steps : 1;
+    const int n_steps = MULTI ? (stop_mid ? pa.mid_step : ca.n_steps) : 1;        // (the verdict is known: no exit from inside the loop)
     // output buffers of this step / of the next one: swapped at the end of every step (scalar moves; a select on the
     // step's parity made the compiler keep both sets of per-lane addresses alive across the loop -- and spill them)
     float* obs_dst = v.obs; float* obs_nxt = MULTI ? ca.obs_odd : v.obs;
     uint8_t* done_dst = v.is_done_out; uint8_t* done_nxt = v.is_done;
     float* rew_dst = rewards; float* rew_nxt = MULTI ? ca.rewards_odd : rewards;
+    const int mid_step = MULTI ? pa.mid_step : 0;          // > 0: the launch covers two check intervals, the first one mid_step steps long
     for (int i = 0; i < n_steps; ++i) {
         // In a chunk, everything derived from the lane's position in its table (seat numbers, `seat < A` masks, ...)
         // is re-derived inside the step: hoisted out of the loop those lane masks filled the scalar registers and were
@@ -672,6 +726,12 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
         }
         STAMP(9);   // observation stores issued
         if ((PH & PULSE_PH_ADVANCE) && j == 0) sto_in_loop(done_dst, ut, (uint8_t)(done ? 1 : 0));      // ping-pong buffer: always written
+        if (MULTI && i + 1 == mid_step) {        // the check point in the middle of a paired launch
+            StepKernargsPtr ka = (StepKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const int c = __popcll(__ballot(done && j == 0));
+            if ((threadIdx.x & 63) == 0) stg(ka->pa.wave_done_mid, (uint32_t)(blockIdx.x * (kStepBlock / 64) + (threadIdx.x >> 6)) * 4u, (uint32_t)c);
+        }
         if (MULTI) {
             float* fo = obs_dst; obs_dst = obs_nxt; obs_nxt = fo;
             uint8_t* fd = done_dst; done_dst = done_nxt; done_nxt = fd;
@@ -960,6 +1020,23 @@ int pulse_timer_collect(void* timer, float* sum_ms, int32_t* n_launches, int64_t
     return 0;
 }
 
+namespace {
+// one chunk launch of a paired sequence (pulse_internal.h: StopRulePair)
+void launch_pair(const PulsePokerView& v_even, const PulsePokerView& v_odd, uint64_t packed, uint64_t seed, uint64_t step_counter0,
+                 uint64_t table_id0, int64_t* actions, float* rewards_even, float* rewards_odd, int n_steps, int chunk_steps,
+                 const pulse::StopRulePair& plan, hipStream_t st) {
+    PolicyArgs pa{packed, seed, step_counter0, table_id0, plan.wave_done_fin, plan.carry[0].partials, plan.carry[0].n, plan.carry[0].host, plan.carry[0].seq};
+    pa.carry2_partials = plan.carry[1].partials; pa.carry2_n = plan.carry[1].n; pa.carry2_host = plan.carry[1].host; pa.carry2_seq = plan.carry[1].seq;
+    if (pa.carry_n == 0 && pa.carry2_n > 0) {        // (cannot happen: carries are filled in order; kept for safety)
+        pa.carry_partials = pa.carry2_partials; pa.carry_n = pa.carry2_n; pa.carry_host = pa.carry2_host; pa.carry_seq = pa.carry2_seq; pa.carry2_n = 0;
+    }
+    pa.wave_done_mid = plan.wave_done_mid; pa.mid_step = plan.n_chunks == 2 ? chunk_steps : 0;
+    pa.verdict_host = plan.verdict_host; pa.verdict_dev = plan.verdict_dev; pa.verdict_id = plan.launch_id;
+    const ChunkArgs ca{v_odd.obs, rewards_odd, n_steps};
+    launch_chunk(v_even, actions, rewards_even, pa, ca, st);
+}
+}  // namespace
+
 int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                         uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions, float* rewards_even,
                         float* rewards_odd, int32_t n_steps, void* timer, void* stoprule, void* stream) {
@@ -1012,10 +1089,48 @@ int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView
         return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout_until: bad argument");
     if (int rc = pulse::check_view(v_even, "pulse_poker_rollout_until")) return rc;
     if (int rc = pulse::check_view(v_odd, "pulse_poker_rollout_until")) return rc;
+    if (!actions || !rewards_even || !rewards_odd || !agent_types) return pulse::fail(PULSE_EINVAL, "pulse_poker_rollout_until: null argument");
     PulseTimer* tm = static_cast<PulseTimer*>(timer);
     hipStream_t st = (hipStream_t)stream;
     const bool per_step = (v_even->flags & PULSE_VIEW_NO_CHUNK) != 0;
+    PulseStopRule* rule = static_cast<PulseStopRule*>(stoprule);
     int done = 0, parity = 0, verdict = 0;
+    // ---- paired launches: with the lag-1 rule ONE launch runs up to two check intervals and takes the rule's verdicts on
+    // the two check points before them itself (pulse_internal.h: StopRulePair) -- half as many state load bursts and
+    // store tails per episode, the same episodes step for step.  (PULSE_VIEW_NO_PAIRS / lag 0 / lag 2 / RCCL: one check
+    // interval per launch, below.)
+    const int n_waves_chunk = (int)(((long long)v_even->n_games * lanes_for(*v_even, true) + 63) / 64);
+    const bool pairs = !per_step && !(v_even->flags & PULSE_VIEW_NO_PAIRS) && chunk_steps > 1 && v_even->n_games > 0 &&
+                       pulse::stoprule_pairs_supported(rule, n_waves_chunk);
+    if (pairs) {
+        const uint64_t packed = pulse::pack_types(agent_types, v_even->n_players);
+        while (done < max_steps && !verdict) {
+            const int left = max_steps - done;
+            const int k = left >= 2 * chunk_steps ? 2 : 1;
+            const int n = k == 2 ? 2 * chunk_steps : (left < chunk_steps ? left : chunk_steps);
+            pulse::StopRulePair plan;
+            const int c = pulse::stoprule_pair_claim(rule, n_waves_chunk, k, &plan);
+            if (c < 0) return c;
+            if (c == 1) { verdict = 1; break; }
+            if (tm && time_every > 0 && !tm->open && (tm->calls % time_every) == 0) if (int rc = timer_begin(tm, st)) return rc;
+            if (tm) ++tm->calls;
+            launch_pair(parity ? *v_odd : *v_even, parity ? *v_even : *v_odd, packed, seed, step_counter0 + (uint64_t)done, table_id0, actions,
+                        parity ? rewards_odd : rewards_even, parity ? rewards_even : rewards_odd, n, chunk_steps, plan, st);
+            if (int rc = pulse::finish_launch("pulse_poker_rollout_until")) return rc;
+            if (int rc = pulse::stoprule_pair_commit(rule, &plan, n_waves_chunk, st)) return rc;
+            int chunks_run = 0;
+            if (int rc = pulse::stoprule_pair_verdict(rule, &plan, &chunks_run, &verdict)) return rc;
+            const int ran = chunks_run == k ? n : chunks_run * chunk_steps;
+            done += ran; parity ^= ran & 1;
+            if (tm && tm->open) {
+                tm->open_launches += 1; tm->open_steps += ran;
+                if (tm->open_launches >= kTimedSpan) timer_end(tm, st);
+            }
+        }
+        if (tm && tm->open) timer_end(tm, st);
+        *steps_done = done; *over = verdict;
+        return 0;
+    }
     while (done < max_steps && !verdict) {
         const int n = chunk_steps < max_steps - done ? chunk_steps : max_steps - done;
         // an event pair brackets kTimedSpan consecutive chunks, every time_every-th chunk opens one

@@ -111,6 +111,7 @@ int pulse_comm_destroy(void* comm) {
 namespace {
 constexpr int kSlots = 4;                 // check points in flight: lag < kSlots
 constexpr int kMaxPartials = 1024;        // workgroups of the flag-counting kernel
+constexpr int kVerdictCopies = 64, kVerdictStride = 16;     // a relayed verdict word: 64 copies, one 128-byte line each (poker_step.hip)
 
 // What the host polls, in coherent pinned memory: the counts of one check point, then its sequence number (written
 // last, behind a system-scope fence) -- the host learns of a result a microsecond after the kernel wrote it, without
@@ -221,6 +222,12 @@ struct PulseStopRule {
     // shared-memory exchange
     PulseShm* shm; int rank, world;
     long long side_launches;              // check points that went through the side stream (sum -> all-reduce -> publish)
+    // paired launches (pulse_internal.h: StopRulePair)
+    long long* verdict_host;              // [kSlots] pinned: {launch id << 8 | flags}, written by the host
+    long long* verdict_dev;               // [kSlots] device: the same word, relayed by thread 0 of the launch
+    long long launches;                   // paired launches issued so far (ids start at 1)
+    long long verdicts_known;             // check points below this index have been read and did not end the episode ...
+    bool over_known;                      // ... unless this is set: check point verdicts_known - 1 did
 };
 
 namespace {
@@ -299,6 +306,70 @@ int stoprule_commit(PulseStopRule* h, int n_partials, hipStream_t st) {
     return 0;
 }
 
+
+// ---- paired launches (pulse_internal.h: StopRulePair)
+bool stoprule_pairs_supported(const PulseStopRule* h, int n_partials) {
+    return h && h->lag == 1 && h->mode != kModeRccl && n_partials > 0 && n_partials <= h->max_partials;
+}
+
+namespace {
+// the count of check point c (this episode's), job-wide; reads it once per check point, in index order
+int pair_count(PulseStopRule* h, long long c, bool* over) {
+    if (c < h->verdicts_known) { *over = false; return 0; }            // read before: it did not end the episode (or we would not be here)
+    if (int rc = wait_published(h, c)) return rc;
+    const int slot = (int)(c % kSlots);
+    long long glob = h->host[slot].global;
+    if (h->mode == kModeShm) { int64_t total = 0; if (int rc = pulse_shm_all_sum(h->shm, c, h->host[slot].local, &total)) return rc; glob = total; }
+    *over = (double)glob > h->threshold * (double)h->n_global;
+    h->verdicts_known = c + 1; h->over_known = *over;
+    return 0;
+}
+}  // namespace
+
+int stoprule_pair_claim(PulseStopRule* h, int n_partials, int n_chunks, StopRulePair* plan) {
+    if (!plan || n_chunks < 1 || n_chunks > 2 || !stoprule_pairs_supported(h, n_partials)) return fail(PULSE_EINVAL, "stop rule: paired launch not possible with this handle");
+    if (h->over_known) return 1;                                       // a count read earlier already ended the episode
+    const long long a = h->submitted;
+    *plan = StopRulePair{};
+    plan->first_check_point = a; plan->n_chunks = n_chunks;
+    plan->launch_id = ++h->launches;
+    plan->verdict_host = h->verdict_host + (plan->launch_id % kSlots);
+    plan->verdict_dev = h->verdict_dev + (plan->launch_id % kSlots) * kVerdictCopies * kVerdictStride;
+    uint32_t* first = h->partials_dev + (size_t)(a % kSlots) * h->max_partials;
+    uint32_t* second = h->partials_dev + (size_t)((a + 1) % kSlots) * h->max_partials;
+    plan->wave_done_mid = n_chunks == 2 ? first : nullptr;
+    plan->wave_done_fin = n_chunks == 2 ? second : first;
+    // carries: this episode's check points a - 2, a - 1 whose publication nobody has enqueued yet
+    int k = 0;
+    for (long long c = a - 2; c < a; ++c) {
+        if (c < h->epoch_first || c < h->scheduled) continue;
+        const int ps = (int)(c % kSlots);
+        plan->carry[k++] = StopRuleCarry{h->partials_dev + (size_t)ps * h->max_partials, h->n_partials[ps], reinterpret_cast<long long*>(h->host + ps), c + 1};
+    }
+    if (h->scheduled < a) h->scheduled = a;
+    return 0;
+}
+
+int stoprule_pair_commit(PulseStopRule* h, const StopRulePair* plan, int n_partials, hipStream_t st) {
+    for (int i = 0; i < plan->n_chunks; ++i) h->n_partials[(plan->first_check_point + i) % kSlots] = n_partials;
+    h->last_stream = st;
+    h->submitted = plan->first_check_point + plan->n_chunks;
+    return 0;
+}
+
+int stoprule_pair_verdict(PulseStopRule* h, const StopRulePair* plan, int* chunks_run, int* over) {
+    const long long a = plan->first_check_point;
+    bool skip = false, stop = false;
+    if (a - 2 >= h->epoch_first) if (int rc = pair_count(h, a - 2, &skip)) return rc;
+    if (!skip && a - 1 >= h->epoch_first) if (int rc = pair_count(h, a - 1, &stop)) return rc;
+    // (stop_mid only means something to a launch of two chunks; a one-chunk launch whose chunk is the episode's last runs it)
+    const long long word = (plan->launch_id << 8) | (skip ? 1 : 0) | (stop && plan->n_chunks == 2 ? 2 : 0);
+    __atomic_store_n(const_cast<long long*>(plan->verdict_host), word, __ATOMIC_RELEASE);
+    *chunks_run = skip ? 0 : (stop ? 1 : plan->n_chunks);
+    *over = (skip || stop) ? 1 : 0;
+    return 0;
+}
+
 }  // namespace pulse
 
 extern "C" {
@@ -319,6 +390,9 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->partials_dev), (size_t)kSlots * h->max_partials * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->pair_dev), kSlots * 2 * sizeof(long long));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->host), kSlots * sizeof(Published), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->verdict_host), kSlots * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->verdict_dev), kSlots * kVerdictCopies * kVerdictStride * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(h->verdict_dev, 0, kSlots * kVerdictCopies * kVerdictStride * sizeof(long long));
     if (e == hipSuccess && h->mode == kModeRccl) {
         e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
         for (int i = 0; i < kSlots && e == hipSuccess; ++i) {
@@ -334,6 +408,7 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
         return code;
     }
     std::memset(h->host, 0, kSlots * sizeof(Published));
+    std::memset(h->verdict_host, 0, kSlots * sizeof(long long));
     if (h->mode == kModeShm) {
         void* shm = nullptr;
         if (int rc = pulse_shm_create(shm_name, rank, world, &shm)) { (void)pulse_stoprule_destroy(h); return rc; }
@@ -357,6 +432,8 @@ int pulse_stoprule_destroy(void* handle) {
     if (h->partials_dev) (void)hipFree(h->partials_dev);
     if (h->pair_dev) (void)hipFree(h->pair_dev);
     if (h->host) (void)hipHostFree(h->host);
+    if (h->verdict_host) (void)hipHostFree(h->verdict_host);
+    if (h->verdict_dev) (void)hipFree(h->verdict_dev);
     delete h;
     return 0;
 }
@@ -415,6 +492,8 @@ int pulse_stoprule_drain(void* handle) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_drain: null argument");
     h->epoch_first = h->submitted;           // check points of the finished episode never decide anything again
+    h->verdicts_known = h->submitted; h->over_known = false;
+    if (h->mode != kModeRccl && h->scheduled < h->submitted) h->scheduled = h->submitted;     // ... and need no publication
     return 0;
 }
 

@@ -51,7 +51,7 @@ _ROWS = ("stacks", "current_round_bet", "total_invested", "status")
 _TRACKED = frozenset(_I32_SCALARS + _BOOL_SCALARS + _ROWS + ("hands", "board", "decks", "equities", "obs",
                                                              "w1", "w2", "K", "alpha", "hand_ranks",
                                                              "active_players", "n_players", "n_games", "max_players",
-                                                             "use_eval_cache", "obs_staging", "chunked_rollout", "chunk_four_lanes"))
+                                                             "use_eval_cache", "obs_staging", "chunked_rollout", "chunk_four_lanes", "paired_launches"))
 
 
 class PokerGPU(_EnvBase):
@@ -101,6 +101,7 @@ class PokerGPU(_EnvBase):
         self.obs_staging = True          # observations leave as LDS-staged 16-byte bursts (needs n_games % 16 == 0)
         self.chunked_rollout = True      # rollout(): one launch per chunk of steps instead of one per step
         self.chunk_four_lanes = False    # chunk launches: four lanes per table also where two are the default (<= 10 seats)
+        self.paired_launches = True      # rollout_until(): two check intervals per launch under the lag-1 rule
         # opt-in: successive steps write their observation into two alternating buffers, so the tensor a step returned
         # stays intact through the NEXT step (a trainer then needs no copy of the pre-step observation).  Off: the
         # reference's single persistent buffer (PokerGPU.py:633).
@@ -232,7 +233,7 @@ class PokerGPU(_EnvBase):
             v.n_games, v.n_players, v.active_players, v.max_players = N, P, A, self.max_players
             v.obs_size, v.hand_ranks_len = self.obs_size, hr.numel()
             v.flags = ((0 if self.obs_staging else _native.VIEW_NO_OBS_STAGING) | (0 if self.chunked_rollout else _native.VIEW_NO_CHUNK)
-                       | (_native.VIEW_FOUR_LANES if self.chunk_four_lanes else 0))
+                       | (_native.VIEW_FOUR_LANES if self.chunk_four_lanes else 0) | (0 if self.paired_launches else _native.VIEW_NO_PAIRS))
             v.hand_ranks = hr.data_ptr()
             for k, p in ptr.items():
                 setattr(v, k, p)

@@ -887,6 +887,51 @@ def test_native_episode_loop_equals_rollout_plus_verdict_per_chunk(lag):
     ra.close(); rb.close()
 
 
+@pytest.mark.parametrize("N", [4096, 65536, 98304], ids=["4096", "65536-bench-size", "98304-slim-lds-image"])
+def test_paired_launches_run_the_episodes_of_one_chunk_per_launch(N):
+    """pulse_poker_rollout_until with the lag-1 rule runs TWO check intervals per launch and lets the launch take the
+    rule's verdicts on the two check points before it (the launch runs two chunks, one, or none).
+    Against the same loop with one check interval per launch (PULSE_VIEW_NO_PAIRS): the same number of steps, the same
+    verdict and bit-identical memory (state, both observation / reward / done buffers, actions) for every episode --
+    episodes cut by caps of 5, 10, 13, 15, 22 and 40 steps (launches of one chunk, of a remainder, mid-episode call
+    boundaries), episodes the rule ends after an even and after an odd number of chunks, and a following episode that
+    starts from whatever the previous one left pending."""
+    from pulselib_amd.stoprule import LaggedDoneCount
+    dev = torch.device(DEV)
+    kw = dict(n_players=6, max_players=10, n_games=N, seed=21, table_id0=3)
+    a, b = _gpu_env(**kw), _gpu_env(**kw)
+    b.paired_launches = False
+    ra, rb = LaggedDoneCount(dev, N, 0.8, lag=1), LaggedDoneCount(dev, N, 0.8, lag=1)
+    types = [1, 3, 2, 4, 5, 1]
+    acts = [torch.zeros(N, dtype=torch.long, device=dev) for _ in range(2)]
+    gstep, ends = 0, set()
+    for e, caps in enumerate(((60,), (13,), (22,), (60,), (5, 5, 10, 40), (15, 5, 40), (10, 10, 10, 10, 20), (40,))):
+        A = (6, 5, 2, 4, 6, 3, 6, 5)[e]
+        for env, rule in ((a, ra), (b, rb)):
+            env.reset(options={"active_players": A, "rotation": e})
+            rule.drain()
+        total = 0
+        for cap in caps:                      # several calls inside one episode: a block boundary of the bench falls anywhere
+            got = a.rollout_until(types, acts[0], 5, cap, gstep + total, ra)
+            want = b.rollout_until(types, acts[1], 5, cap, gstep + total, rb)
+            assert got == want, f"episode {e} cap {cap}: paired {got}, single {want}"
+            total += got[0]
+            for name in ROLLOUT_MEMORY:
+                np.testing.assert_array_equal(to_np(getattr(a, name)), to_np(getattr(b, name)), err_msg=f"episode {e} cap {cap} {name}")
+            for k in range(2):
+                np.testing.assert_array_equal(to_np(a._obs_bufs[k]), to_np(b._obs_bufs[k]), err_msg=f"episode {e} obs buffer {k}")
+                np.testing.assert_array_equal(to_np(a._rewards[k]), to_np(b._rewards[k]), err_msg=f"episode {e} rewards buffer {k}")
+                np.testing.assert_array_equal(to_np(a._done_bufs[k]), to_np(b._done_bufs[k]), err_msg=f"episode {e} done buffer {k}")
+            assert a._pp == b._pp
+            np.testing.assert_array_equal(to_np(acts[0]), to_np(acts[1]))
+            if got[1]:
+                ends.add((total // 5) % 2)
+                break
+        gstep += total
+    assert ends == {0, 1}, f"the rule must end episodes after even and odd numbers of chunks (got {ends})"
+    ra.close(); rb.close()
+
+
 def test_rccl_exchange_with_one_rank_decides_like_the_local_rule():
     """exchange="rccl": the stop rule's count goes through a NATIVE RCCL communicator (librccl bound with dlopen,
     csrc/stoprule.hip) -- one int64 all-reduce per check point on the rule's side stream, handed over by events.  One
