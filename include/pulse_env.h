@@ -138,15 +138,26 @@ int pulse_poker_phases(const PulsePokerView* v, uint32_t phases, const int64_t* 
  *                    Philox4x32-10(seed, table id + table_id0, episode) (replaces rand().argsort, :86)
  *   decks_out      : v->decks is const in the view; reset writes through this pointer.
  *   rotation       : torch.roll shift of the stack rows                                     (:104-110)
- *   shuffle_key_bits : the device shuffle ranks 52 Philox words per table, equal words keeping card order;
- *                    0 (or >= 32) uses whole words.  A small value keeps only that many top bits and so
- *                    forces ties: a hook for the tests of the tie-break, not for production use. */
+ *   shuffle_key_bits : the device shuffle orders the 52 cards of a table by the top 26 bits of one Philox word each
+ *                    (torch.rand's keys have 24), equal keys keeping card order; 1..25 keeps fewer bits and so
+ *                    forces ties: a hook for the tests of the tie-break, not for production use.  0 = 26.
+ *   stats_rewards / stats_out : NULL, or the episode statistics of the episode that ENDS here, taken before the state
+ *                    is overwritten: the sum of stats_rewards[t] (device fp32[n_games], the last step's rewards) and the
+ *                    number of tables with is_done (what a rank all-reduces per episode, scripts/Poker/trainGPU.py:96,
+ *                    104) are ADDED into stats_out, device double[PULSE_STATS_SLOTS * PULSE_STATS_STRIDE]: accumulator k
+ *                    is {stats_out[k * STRIDE] = reward sum, stats_out[k * STRIDE + 1] = done count}, a wavefront adds to
+ *                    accumulator (its index mod SLOTS); the total is the sum over k.  (Spread because same-address
+ *                    atomics serialise.)  No launch of its own. */
+#define PULSE_STATS_SLOTS 256
+#define PULSE_STATS_STRIDE 16
 typedef struct PulsePokerResetOpts {
     int32_t first, starting_bbs, max_bbs, rotation;
     uint64_t seed, episode, table_id0;
     const int32_t* prefixed_decks;
     int32_t* decks_out;
     int32_t shuffle_key_bits, reserved0;
+    const float* stats_rewards;
+    double* stats_out;
 } PulsePokerResetOpts;
 int pulse_poker_reset(const PulsePokerView* v, const PulsePokerResetOpts* o, void* stream);
 

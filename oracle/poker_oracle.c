@@ -428,11 +428,12 @@ void oracle_philox4x32(uint64_t seed, uint64_t subseq, uint64_t offset, uint32_t
 /* ---- deck shuffle (replaces torch.rand(N,52).argsort(dim=1)+1, PokerGPU.py:86) -----------------
  * The framework's own definition (the reference's draw is not reproducible across devices): card c
  * (0..51) gets key word (c & 3) of Philox4x32-10(seed, global table id, episode*16 + (c >> 2)),
- * optionally cut to its top key_bits bits; the deck lists cards + 1 by ascending key, equal keys in
- * card order (a stable sort -- here an insertion sort, the HIP kernels count ranks instead). */
+ * cut to its top key_bits bits (1..26; anything else means 26 -- torch.rand's float32 keys have 24); the deck lists
+ * cards + 1 by ascending key, equal keys in card order (a stable sort -- here an insertion sort; the HIP kernel sorts
+ * the words key << 6 | card with a bitonic network, which is the same order). */
 void oracle_shuffle_decks(uint64_t seed, uint64_t table_id0, uint64_t episode, int key_bits, int n_tables,
                           int32_t* decks) {
-    const int shift = (key_bits > 0 && key_bits < 32) ? 32 - key_bits : 0;
+    const int shift = 32 - ((key_bits > 0 && key_bits <= 26) ? key_bits : 26);
     #pragma omp parallel for schedule(static)               /* tables are independent; bench.py's CPU leg shuffles 65,536 per episode */
     for (int t = 0; t < n_tables; t++) {
         uint32_t key[52]; int32_t* d = decks + (size_t)t * 52;

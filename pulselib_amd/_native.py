@@ -16,6 +16,7 @@ _CSRC = _PKG / "csrc"
 _LIB: C.CDLL | None = None
 
 HANDRANKS_LEN = 32487834
+STATS_SLOTS, STATS_STRIDE = 256, 16          # PulsePokerResetOpts.stats_out layout (include/pulse_env.h)
 MAX_SEATS = 16
 
 # phase bits (include/pulse_env.h)
@@ -53,7 +54,7 @@ class PokerResetOpts(C.Structure):
     _fields_ = [("first", C.c_int32), ("starting_bbs", C.c_int32), ("max_bbs", C.c_int32), ("rotation", C.c_int32),
                 ("seed", C.c_uint64), ("episode", C.c_uint64), ("table_id0", C.c_uint64),
                 ("prefixed_decks", C.c_void_p), ("decks_out", C.c_void_p),
-                ("shuffle_key_bits", C.c_int32), ("reserved0", C.c_int32)]
+                ("shuffle_key_bits", C.c_int32), ("reserved0", C.c_int32), ("stats_rewards", C.c_void_p), ("stats_out", C.c_void_p)]
 
 
 class QNet(C.Structure):

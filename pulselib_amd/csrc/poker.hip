@@ -58,14 +58,59 @@ __global__ __launch_bounds__(kBlock) void poker_eval_closed_form_kernel(const in
 }
 
 // ---------------------------------------------------------------- reset (PokerGPU.py:73-157)
-// shuffle keys keep their top `shuffle_key_bits` bits (0 = all 32; fewer bits force ties, for the tests)
+// shuffle keys keep their top `shuffle_key_bits` bits (1..26; anything else: 26)
 __device__ __forceinline__ int key_shift(const PulsePokerResetOpts& o) {
-    return (o.shuffle_key_bits > 0 && o.shuffle_key_bits < 32) ? 32 - o.shuffle_key_bits : 0;
+    return 32 - ((o.shuffle_key_bits > 0 && o.shuffle_key_bits <= 26) ? o.shuffle_key_bits : 26);
+}
+
+// ---- bitonic sort of 64 words over the 16 lanes of a table (one DPP row), four words per lane: element i = 4 * lane + q.
+// Every merge starts with the mirror exchange i <-> i ^ (k - 1) and continues with i <-> i ^ j for j = k/4 ... 1, so
+// that every compare-exchange is "the lower index keeps the smaller word" -- no direction flags.  Exchanges with
+// j < 4 stay inside a lane (two min/max pairs); the others pair lanes l <-> l ^ m, each a single DPP pattern of a row:
+// m = 1, 2, 3 quad_perm, 7 row_half_mirror, 15 row_mirror, 4 two rotations.  Keys are unique (the card index sits in
+// their low six bits), so the sorted order is the stable order of the keys alone.
+constexpr int kQuadMirror = 0x1B, kRowHalfMirror = 0x141, kRowMirror = 0x140, kRowRor12 = 0x12C;    // quad_perm:[3,2,1,0]
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v) { return (uint32_t)dpp_mov<CTRL>((int)v); }
+__device__ __forceinline__ void cx(uint32_t& lo, uint32_t& hi) { const uint32_t a = min(lo, hi), b = max(lo, hi); lo = a; hi = b; }
+// partner values (register q of the partner lane for plain exchanges, register 3 - q for mirrors) -> keep min or max
+template <int CTRL, bool MIRROR> __device__ __forceinline__ void cx_lanes(uint32_t (&a)[4], bool lower) {
+    uint32_t p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = dpp_u<CTRL>(a[MIRROR ? 3 - q : q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = lower ? min(a[q], p[q]) : max(a[q], p[q]);
+}
+__device__ __forceinline__ void cx_lanes_xor4(uint32_t (&a)[4], int lane) {          // l <-> l ^ 4: no single DPP pattern
+    const bool lower = (lane & 4) == 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t up = dpp_u<kRowRor12>(a[q]), dn = dpp_u<kRowRor4>(a[q]);    // ror:n -- lane l reads lane (l - n) mod 16
+        const uint32_t p = lower ? up : dn;
+        a[q] = lower ? min(a[q], p) : max(a[q], p);
+    }
+}
+__device__ __forceinline__ void sort64_in_row(uint32_t (&a)[4], int lane) {
+    const bool b0 = (lane & 1) == 0, b1 = (lane & 2) == 0, b2 = (lane & 4) == 0, b3 = (lane & 8) == 0;
+    cx(a[0], a[1]); cx(a[2], a[3]);                                                   // k = 2
+    cx(a[0], a[3]); cx(a[1], a[2]); cx(a[0], a[1]); cx(a[2], a[3]);                   // k = 4
+    cx_lanes<kQuadXor1, true>(a, b0);                                                 // k = 8: mirror (l ^ 1)
+    cx(a[0], a[2]); cx(a[1], a[3]); cx(a[0], a[1]); cx(a[2], a[3]);
+    cx_lanes<kQuadMirror, true>(a, b1);                                               // k = 16: mirror (l ^ 3)
+    cx_lanes<kQuadXor1, false>(a, b0);
+    cx(a[0], a[2]); cx(a[1], a[3]); cx(a[0], a[1]); cx(a[2], a[3]);
+    cx_lanes<kRowHalfMirror, true>(a, b2);                                            // k = 32: mirror (l ^ 7)
+    cx_lanes<kQuadXor2, false>(a, b1);
+    cx_lanes<kQuadXor1, false>(a, b0);
+    cx(a[0], a[2]); cx(a[1], a[3]); cx(a[0], a[1]); cx(a[2], a[3]);
+    cx_lanes<kRowMirror, true>(a, b3);                                                // k = 64: mirror (l ^ 15)
+    cx_lanes_xor4(a, lane);
+    cx_lanes<kQuadXor2, false>(a, b1);
+    cx_lanes<kQuadXor1, false>(a, b0);
+    cx(a[0], a[2]); cx(a[1], a[3]); cx(a[0], a[1]); cx(a[2], a[3]);
 }
 
 template <bool SHUFFLE>
 __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerView v, const PulsePokerResetOpts o) {
-    __shared__ uint32_t keys[kBlock / kLanes][52];
     __shared__ int32_t deck_s[kBlock / kLanes][52];
     __shared__ uint8_t valid_s[kBlock / kLanes];          // the table's 2A+5 cards are distinct and in 1..52 (its cache entry can be made)
     const int gt = blockIdx.x * kBlock + threadIdx.x;
@@ -80,41 +125,25 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     // The table's 16 lanes sit in one wavefront, LDS ops of a wavefront retire in order, so the
     // wavefront-scope fences below are all the synchronisation the staging needs.
     if (SHUFFLE) {
+        // card c = 4 s + q carries the word (key << 6 | c), key = the top bits of word q of lane s's Philox call; lanes
+        // 13..15 carry twelve fillers above every card.  Sorted, element i sits in register i & 3 of lane i >> 2, and
+        // the deck is the cards in that order: rand().argsort() + 1 (PokerGPU.py:86) with Philox keys.  (Round 2 counted,
+        // for every card, the keys below its own -- 52 x 4 compare + add-with-carry per lane, 470 vector instructions
+        // per wavefront against ~190 for the network.)
+        uint32_t a[4];
+        const int ks = key_shift(o);
         if (s < 13) {
             const U4 r = philox4x32(o.seed, o.table_id0 + (uint64_t)t, o.episode * 16 + (uint64_t)s);
-            const int ks = key_shift(o);
-            keys[g][4 * s + 0] = r.x >> ks; keys[g][4 * s + 1] = r.y >> ks; keys[g][4 * s + 2] = r.z >> ks; keys[g][4 * s + 3] = r.w >> ks;
+            a[0] = (r.x >> ks) << 6 | (uint32_t)(4 * s); a[1] = (r.y >> ks) << 6 | (uint32_t)(4 * s + 1);
+            a[2] = (r.z >> ks) << 6 | (uint32_t)(4 * s + 2); a[3] = (r.w >> ks) << 6 | (uint32_t)(4 * s + 3);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = 0xFFFFFFC0u | (uint32_t)(4 * s + q);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // card c (0..51) lands at position #{keys < key[c]} (ties by index): deck[pos] = c + 1.  Without a tie
-        // the strict count alone is the position (one compare + one add-with-carry per pair); with one, the
-        // table's strict counts sum to less than 0 + 1 + ... + 51 and the wavefront (rarely: ~3e-7 per table)
-        // recounts with the index tie-break.
-        uint32_t kc[4] = {0, 0, 0, 0}; int pos[4] = {0, 0, 0, 0};
+        sort64_in_row(a, s);
         if (s < 13) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) kc[q] = keys[g][4 * s + q];
-            for (int j = 0; j < 52; ++j) {
-                const uint32_t kj = keys[g][j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pos[q] += kj < kc[q];
-            }
-        }
-        const int psum = row_sum(pos[0] + pos[1] + pos[2] + pos[3]);
-        if (__any(psum != 1326)) {
-            if (s < 13) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pos[q] = 0;
-                for (int j = 0; j < 52; ++j) {
-                    const uint32_t kj = keys[g][j];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pos[q] += (kj < kc[q]) || (kj == kc[q] && j < 4 * s + q);
-                }
-            }
-        }
-        if (s < 13) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) deck_s[g][pos[q]] = 4 * s + q + 1;
+            for (int q = 0; q < 4; ++q) deck_s[g][4 * s + q] = (int32_t)(a[q] & 63u) + 1;
         }
     } else {
         const int32_t* src = o.prefixed_decks + (size_t)t * 52;
@@ -123,6 +152,26 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int c = s; c < 52; c += kLanes) dk[c] = deck_s[g][c];
 
+    // statistics of the episode that ends here (the caller's per-episode sums, trainGPU.py:96,104), before its flags go
+    if (o.stats_out) {
+        float rf = 0.0f; bool dn = false;
+        if (s == 0) { rf = o.stats_rewards[t]; dn = v.is_done[t] != 0; }
+        const int d = __popcll(__ballot(dn));                       // (rows of tables past the end have left: they do not vote)
+        const int t_row0 = t - ((threadIdx.x & 63) >> 4);           // first table of this wavefront
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // lane 16 k holds table k's reward
+            const float x = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rf), 16 * k));
+            if (t_row0 + k < v.n_games) r += (double)x;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            // one of PULSE_STATS_SLOTS accumulators, a cache line each: atomics of all wavefronts onto ONE address take
+            // ~5 ns apiece one after the other (16,384 wavefronts x 2: this kernel ran 360 us instead of 25)
+            double* slot = o.stats_out + (size_t)((gt >> 6) & (PULSE_STATS_SLOTS - 1)) * PULSE_STATS_STRIDE;
+            if (r != 0.0) atomicAdd(slot, r);
+            if (d) atomicAdd(slot + 1, (double)d);
+        }
+    }
     // stacks: refill busted / over-max, then torch.roll by `rotation` (:101-110)
     int st = o.starting_bbs;
     if (seat && !o.first) {

@@ -327,12 +327,31 @@ class PokerGPU(_EnvBase):
         o.prefixed_decks = deck_tensor.data_ptr() if deck_tensor is not None else None
         o.decks_out = self.decks.data_ptr()
         o.shuffle_key_bits = int(getattr(self, "_shuffle_key_bits", 0))      # test hook (pulse_env.h)
+        stats = options.get("episode_stats")
+        if stats is not None:
+            # (rewards fp32[N], acc float64[STATS_SLOTS, STATS_STRIDE] from new_episode_stats()): the sums of the episode that
+            # ends with this reset -- acc[:, 0].sum() += sum(rewards), acc[:, 1].sum() += tables done -- taken by the reset
+            # launch itself before it clears the flags (no launch of their own)
+            rew, out = stats
+            if not (rew.dtype == torch.float32 and rew.numel() == self.n_games and rew.is_contiguous() and out.dtype == torch.float64
+                    and out.numel() == _native.STATS_SLOTS * _native.STATS_STRIDE and out.is_contiguous()
+                    and rew.device == self.device and out.device == self.device):
+                raise ValueError("episode_stats must be (fp32[n_games] rewards, the float64 accumulator of new_episode_stats()) on the environment's device")
+            o.stats_rewards, o.stats_out = rew.data_ptr(), out.data_ptr()
         with self._on_device():
             _native.check(self._lib.pulse_poker_reset(C.byref(v), C.byref(o), self._stream()), "pulse_poker_reset")
         self.button_pos = self.button[0]
         self._has_episode = True
         self.episode += 1
         return self.obs, self.get_info()
+
+    def new_episode_stats(self):
+        """Accumulator for reset(options={"episode_stats": (rewards, acc)}); episode_stats_totals(acc) -> (reward sum, tables done)."""
+        return torch.zeros((_native.STATS_SLOTS, _native.STATS_STRIDE), dtype=torch.float64, device=self.device)
+
+    @staticmethod
+    def episode_stats_totals(acc):
+        return acc[:, :2].sum(dim=0)
 
     # ------------------------------------------------------------------ step (PokerGPU.py:527-633)
     def step(self, actions):

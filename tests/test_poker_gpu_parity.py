@@ -1047,6 +1047,28 @@ def test_stats_kernel_forms():
     assert float(both[1]) == float(done.sum()) and abs(float(both[0]) - float(rew.astype(np.float64).sum())) < 1e-6
 
 
+@pytest.mark.parametrize("N", [4096, 4099, 3], ids=["4096", "ragged-4099", "3-tables"])
+def test_reset_takes_the_ended_episodes_statistics(N):
+    """options["episode_stats"] = (rewards, sums): the reset launch adds the ended episode's reward sum and done count
+    to `sums` before it clears the flags (PulsePokerResetOpts.stats_*) -- what the separate statistics launch did."""
+    env = _gpu_env(n_players=6, max_players=10, n_games=N, seed=8)
+    env.reset(options={"active_players": 6})
+    acts = torch.zeros(N, dtype=torch.long, device=DEV)
+    sums = env.new_episode_stats()
+    want_r, want_d = 0.0, 0
+    for e in range(3):
+        env.rollout([1] * 6, acts, 17 + e, 100 * e)
+        rew = env._rewards[1 - env._pp]
+        want_r += float(rew.double().sum()); want_d += int(env.is_done.sum())
+        assert want_d > 0
+        env.reset(options={"active_players": 5 + e % 2, "rotation": e, "episode_stats": (rew, sums)})
+        got = env.episode_stats_totals(sums).cpu().tolist()
+        assert got[1] == want_d and abs(got[0] - want_r) < 1e-6 * max(1.0, abs(want_r)), (e, got, want_r, want_d)
+        assert int(env.is_done.sum()) == 0
+    with pytest.raises(ValueError, match="episode_stats"):
+        env.reset(options={"episode_stats": (torch.zeros(N, device=DEV), torch.zeros(2, dtype=torch.float64, device=DEV))})      # not the accumulator
+
+
 def test_double_buffered_observations_keep_the_previous_step_intact():
     """double_buffer_obs: same observations as the single persistent buffer, step for step, and the tensor returned by a
     step (or reset) is not touched by the NEXT step -- what the fused trainer relies on instead of copying."""
