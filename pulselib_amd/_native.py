@@ -11,7 +11,7 @@ import subprocess
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-_SO = _PKG / "libpulse_hip.so"
+_SO = Path(os.environ["PULSE_LIB"]) if os.environ.get("PULSE_LIB") else _PKG / "libpulse_hip.so"     # PULSE_LIB: A/B of builds (tools/ab_bench.py)
 _CSRC = _PKG / "csrc"
 _LIB: C.CDLL | None = None
 
