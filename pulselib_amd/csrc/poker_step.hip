@@ -711,7 +711,17 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 const int tw0 = (int)((blockIdx.x * kStepBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
                 const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
                 const int4* src = reinterpret_cast<const int4*>(l_obs);
-                for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
+                constexpr int kBursts = 5;          // two-lane chunk, 40 columns: 32 rows x 160 B = five 1-KiB bursts
+                if (n4 == kBursts * 64) {
+                    // all reads first, then all stores: as a loop over e every pass waited for its own LDS read
+                    // (five exposed LDS latencies per step)
+                    int4 x[kBursts];
+#pragma unroll
+                    for (int u = 0; u < kBursts; ++u) x[u] = src[wlane + 64 * u];
+#pragma unroll
+                    for (int u = 0; u < kBursts; ++u) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)(wlane + 64 * u) * 16u, x[u]);
+                } else
+                    for (int e = wlane; e < n4; e += 64) sto_in_loop(reinterpret_cast<int4*>(obs_dst), blk0 + (uint32_t)e * 16u, src[e]);
                 if (MULTI) {       // the next step's values must not overtake these reads of the slice
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
