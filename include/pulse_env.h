@@ -311,17 +311,36 @@ int pulse_tfe_step(int32_t* boards, int64_t* total_score, const int64_t* actions
                    uint8_t* dones, int32_t n_boards, int32_t n, uint64_t seed, uint64_t board_id0,
                    uint64_t step_counter, void* stream);                                        /* :152-189 */
 
-/* ---- Tabular Q-learning for the batched 2048 roll-out -------------------------------------------
- * Replaces utils/numba.py:5-21 (epsilon-greedy) and :25-39 (update) + the defaultdict of
- * agents/TemperalDifference/QLearningNumba.py:10-37.  keys: device uint64[capacity] (0 = empty),
- * values: device double[capacity,4], both zero-initialised by the caller; capacity and region_slots are
- * powers of two.  region_slots > 0: board g owns slots [g*region_slots, (g+1)*region_slots) (independent
- * learners, race-free); 0: one table shared by all boards (updates applied with a CAS loop). */
+/* ---- tabular Q-learning for the batched 2048 roll-out (utils/numba.py:5-39, agents/TemperalDifference/QLearningNumba.py:10-37)
+ * The reference's `defaultdict(state -> float64[4])` is an open-addressing hash table of 64-byte ENTRIES in HBM:
+ *   entry = { uint64 key (the board packed as 4-bit log2 tiles; 0 = free), double q[4], 24 spare bytes }
+ * -- key and values of a state in ONE memory line.  entries: device memory, capacity * 64 bytes, 64-byte aligned,
+ * zero-initialised by the caller; capacity and region_slots are powers of two.  region_slots > 0: board g owns entries
+ * [g*region_slots, (g+1)*region_slots) (independent learners = copies of the reference agent, race-free, bit-exact);
+ * 0: one table shared by all boards.  Shared table: an update whose single compare-and-swap loses against a concurrent
+ * update of the same cell is deferred, and the deferred transitions of a launch are combined per cell --
+ *   q <- q + (1 - (1 - alpha)^k) (mean of the k targets - q)   (k = 1: numba.py:38-39 itself)
+ * -- with plain atomic adds into the per-launch scratch below (linear in the number of contenders; a CAS retry loop is
+ * quadratic: all boards leave reset from a few hundred states). */
+#define PULSE_QTABLE_ENTRY_BYTES 64
 typedef struct PulseQTable {
-    uint64_t* keys;
-    double* values;
+    void* entries;
     uint64_t capacity, region_slots;
 } PulseQTable;
+/* Scratch of a shared table (NULL for private regions): caller-owned device memory, zero-initialised once.
+ * count uint32[4]; cells uint64[n]; targets double[n]; owner int32[n]; acc_key uint64[acc_slots]; acc_cnt
+ * uint32[acc_slots]; acc_sum double[acc_slots]; n >= n_boards; acc_slots a power of two >= 2 n.  launch_index: the
+ * caller counts its update / rollout_step launches on this scratch (0, 1, 2, ...: its parity picks the list). */
+typedef struct PulseQTableScratch {
+    uint32_t* count;
+    uint64_t* cells;
+    double* targets;
+    int32_t* owner;
+    uint64_t* acc_key;
+    uint32_t* acc_cnt;
+    double* acc_sum;
+    uint32_t n, acc_slots;
+} PulseQTableScratch;
 /* state lookup/insert + epsilon-greedy: actions int64[B] out, slots int64[B] out (-1 = no room: the region is full or
  * 4,096 consecutive slots were taken -- size a shared table for the states a run will visit; such a board acts at
  * random and is not updated) */
@@ -329,9 +348,18 @@ int pulse_qtable_select(const PulseQTable* q, const int32_t* boards, int32_t n_b
                         uint64_t seed, uint64_t board_id0, uint64_t step_counter, int64_t* actions, int64_t* slots,
                         void* stream);
 /* q[s][a] += alpha * ((terminal ? r : r + gamma * max q[s']) - q[s][a]) for every board */
-int pulse_qtable_update(const PulseQTable* q, const int64_t* slots, const int64_t* actions, const int32_t* rewards,
-                        const int32_t* next_boards, const uint8_t* terminal, int32_t n_boards, int32_t n, double alpha,
-                        double gamma, void* stream);
+int pulse_qtable_update(const PulseQTable* q, const PulseQTableScratch* scratch, uint64_t launch_index, const int64_t* slots,
+                        const int64_t* actions, const int32_t* rewards, const int32_t* next_boards, const uint8_t* terminal,
+                        int32_t n_boards, int32_t n, double alpha, double gamma, void* stream);
+/* One roll-out step of B learners in ONE launch: pulse_qtable_select + pulse_tfe_step + pulse_qtable_update with the board
+ * in registers throughout (same draws, same results: the agent's stream (agent_seed, board, agent_step), the
+ * environment's (env_seed, board, env_step >= 1)).  slots_io int64[B]: in = the entry of every board's current state if
+ * the previous step found it, -2 = look it up; out = the entry of the state the move led to.  boards / total_score are
+ * updated in place, actions / rewards / dones written as the three calls would. */
+int pulse_qtable_rollout_step(const PulseQTable* q, const PulseQTableScratch* scratch, uint64_t launch_index, int32_t* boards,
+                              int64_t* total_score, int32_t n_boards, int32_t n, double epsilon, double alpha, double gamma,
+                              uint64_t agent_seed, uint64_t agent_step, uint64_t env_seed, uint64_t env_step, uint64_t board_id0,
+                              int64_t* actions, int32_t* rewards, uint8_t* dones, int64_t* slots_io, void* stream);
 
 /* ---- the learner's action selection (environments/Poker/Player.py:178-253) ---------------------
  * PokerQNetwork.network in eval mode: Linear(state_dim,128) GELU Linear(128,128) GELU [Dropout] Linear(128,64)

@@ -70,7 +70,12 @@ class QNetTrain(C.Structure):
 
 
 class QTable(C.Structure):
-    _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("capacity", C.c_uint64), ("region_slots", C.c_uint64)]
+    _fields_ = [("entries", C.c_void_p), ("capacity", C.c_uint64), ("region_slots", C.c_uint64)]
+
+
+class QTableScratch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("count", "cells", "targets", "owner", "acc_key", "acc_cnt", "acc_sum")] + [
+        ("n", C.c_uint32), ("acc_slots", C.c_uint32)]
 
 
 class BlackjackView(C.Structure):
@@ -122,7 +127,9 @@ SYMBOLS = {
     "pulse_tfe_reset": (C.c_int, [_P, _P, _I32, _I32, _U64, _U64, _P]),
     "pulse_tfe_step": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _U64, _U64, _U64, _P]),
     "pulse_qtable_select": (C.c_int, [_P, _P, _I32, _I32, C.c_double, _U64, _U64, _U64, _P, _P, _P]),
-    "pulse_qtable_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, C.c_double, C.c_double, _P]),
+    "pulse_qtable_update": (C.c_int, [_P, _P, _U64, _P, _P, _P, _P, _P, _I32, _I32, C.c_double, C.c_double, _P]),
+    "pulse_qtable_rollout_step": (C.c_int, [_P, _P, _U64, _P, _P, _I32, _I32, C.c_double, C.c_double, C.c_double, _U64, _U64, _U64, _U64, _U64,
+                                            _P, _P, _P, _P, _P]),
     "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
     "pulse_qnet_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P, _P, _P]),

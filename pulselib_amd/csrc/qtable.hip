@@ -3,17 +3,28 @@
 // The reference keeps `defaultdict(state tuple -> float64[n])` in Python and calls two numba scalars per
 // step and per (single) board: utils/numba.py:5-21 (epsilon-greedy argmax) and :25-39 (Q update), driven
 // by agents/TemperalDifference/QLearningNumba.py:10-37.  Here B boards act and learn per launch:
-//   * the dict is an open-addressing hash table in HBM (uint64 key = the board packed as 4-bit log2
-//     tiles, double[4] values, linear probing, lock-free insert by atomicCAS);
+//   * the dict is an open-addressing hash table in HBM of 64-byte ENTRIES {uint64 key = the board packed as 4-bit log2
+//     tiles, double q[4], 24 spare bytes}: a state's key and values share one memory line, so a lookup costs one random
+//     line instead of two (round 2: keys and values in separate arrays); linear probing, lock-free insert by atomicCAS;
 //   * pulse_qtable_select: look up / insert the state, epsilon-greedy over its four doubles
 //     (first maximal index, as numba.py:13-19), Philox draws keyed by (seed, board id, step);
-//   * pulse_qtable_update: q[s][a] += alpha * (target - q[s][a]), target = r or r + gamma * max q[s'].
+//   * pulse_qtable_update: q[s][a] += alpha * (target - q[s][a]), target = r or r + gamma * max q[s'];
+//   * pulse_qtable_rollout_step: select + the 2048 move (tfe_device.h) + update in ONE launch -- the board stays in
+//     registers, s' found by the update is carried to the next step's select: two random lines per board-step.
 // `region_slots` > 0 gives every board a private region of the table (B independent learners = B copies of
-// the reference, bit-exact and race-free: the parity mode); 0 shares one table between all boards, updates
-// then race benignly (Hogwild) and are applied with a 64-bit CAS loop so no update is torn.
+// the reference, bit-exact and race-free: the parity mode); 0 shares one table between all boards.
+//
+// Shared table, several boards updating ONE entry in the same launch (all boards leave reset from a few hundred two-tile
+// states: ~1,000 contenders per entry).  A CAS retry loop is quadratic there (every round one contender wins, the others
+// start over: the update launch took 5.8 ms at the first step, 37 us once the boards had spread).  Now every update tries
+// its CAS ONCE; those that lose are deferred and combined: a per-launch scratch hash maps the cell to an accumulator,
+// every deferred transition adds its target with plain atomic adds (linear), and one thread per cell applies
+//     q <- q + (1 - (1 - alpha)^k) * (mean of the k targets - q)
+// -- the k transitions applied one after another with the mean of their targets (k = 1: the reference's formula itself).
 #include <hip/hip_runtime.h>
 
 #include "pulse_internal.h"
+#include "tfe_device.h"
 
 namespace {
 
@@ -34,7 +45,20 @@ __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_
     return U4{c0, c1, c2, c3};
 }
 
+// one table entry = one 64-byte line
+struct alignas(64) Entry { unsigned long long key; double q[4]; unsigned long long spare[3]; };
+static_assert(sizeof(Entry) == PULSE_QTABLE_ENTRY_BYTES, "entry layout is part of the ABI");
+
 // board -> key: 4 bits of log2(tile) per cell (0 = empty), row-major, cell 0 in the low nibble.
+__device__ __forceinline__ uint64_t pack_cells(const int* b, int cells) {
+    uint64_t key = 0;
+    for (int i = 0; i < cells; ++i) {
+        const int v = b[i];
+        const uint64_t e = v > 0 ? (uint64_t)min(31 - __clz(v), 15) : 0ull;
+        key |= e << (4 * i);
+    }
+    return key;
+}
 __device__ __forceinline__ uint64_t pack_board(const int32_t* __restrict__ b, int cells) {
     uint64_t key = 0;
     for (int i = 0; i < cells; ++i) {
@@ -54,23 +78,129 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 // thread into a walk over the whole table (262,144 threads x 2^24 slots: a launch that never ends); past the
 // limit the state counts as "no room" like a full region.
 constexpr uint64_t kMaxProbe = 4096;
-__device__ __forceinline__ long long find_or_insert(unsigned long long* keys, uint64_t base, uint64_t slots, uint64_t key) {
+__device__ __forceinline__ long long find_or_insert(Entry* table, uint64_t base, uint64_t slots, uint64_t key) {
     uint64_t h = mix64(key) & (slots - 1);
     const uint64_t limit = slots < kMaxProbe ? slots : kMaxProbe;
     for (uint64_t probe = 0; probe < limit; ++probe) {
         const uint64_t s = base + ((h + probe) & (slots - 1));
-        unsigned long long cur = keys[s];
+        unsigned long long cur = table[s].key;
         if (cur == key) return (long long)s;
         if (cur == 0ull) {
-            cur = atomicCAS(&keys[s], 0ull, (unsigned long long)key);
+            cur = atomicCAS(&table[s].key, 0ull, (unsigned long long)key);
             if (cur == 0ull || cur == key) return (long long)s;
         }
     }
     return -1;
 }
 
-__global__ __launch_bounds__(kBlock) void qtable_select_kernel(unsigned long long* keys, const double* __restrict__ values,
-                                                              uint64_t capacity, uint64_t region_slots,
+// epsilon-greedy (numba.py:5-21): p from words x, y of the board's Philox call, the random action from word z
+__device__ __forceinline__ int choose_action(const U4& r, double epsilon, const double* q, bool have_row) {
+    const double p = (double)(((uint64_t)r.x << 21) ^ (uint64_t)(r.y >> 11)) * (1.0 / 9007199254740992.0);   // 53-bit uniform
+    if (p < epsilon || !have_row) return (int)__umulhi(r.z, 4u);        // numba.py:9-11 random.randint(0, n-1)
+    int a = 0; double mx = q[0];
+    for (int i = 1; i < 4; ++i) if (q[i] > mx) { mx = q[i]; a = i; }    // numba.py:13-19
+    return a;
+}
+
+// ---- deferred updates of a shared table (see the header comment) -------------------------------------------------
+struct Deferred {                 // per-launch scratch, owned by the caller (PulseQTableScratch)
+    unsigned int* count;          // [4]: deferred transitions of the even / odd launch, then the two meeting counters of the follow-up launch
+    unsigned long long* cells;    // [n]: entry index * 4 + action
+    double* targets;              // [n]
+    int* owner;                   // [n]: accumulator index if this transition claimed its cell, else -1
+    unsigned long long* acc_key;  // [acc_slots]: cell + 1 (0 = free)
+    unsigned int* acc_cnt;        // [acc_slots]
+    double* acc_sum;              // [acc_slots]
+    unsigned int acc_slots;       // power of two >= 2 n
+    int parity;
+};
+
+// q[s][a] <- q + alpha (target - q): race-free regions write, shared tables try ONE compare-and-swap and defer on a loss
+__device__ __forceinline__ void apply_update(Entry* table, long long s, int a, double target, double alpha, bool shared_table, const Deferred& d) {
+    double* cell = &table[s].q[a & 3];
+    if (!shared_table) {
+        const double old = *cell;
+        *cell = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));                       // numba.py:38-39
+        return;
+    }
+    unsigned long long* raw = reinterpret_cast<unsigned long long*>(cell);
+    const unsigned long long seen = *raw;
+    const double old = __longlong_as_double((long long)seen);
+    const double upd = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));
+    const bool lost = atomicCAS(raw, seen, (unsigned long long)__double_as_longlong(upd)) != seen;
+    // append the losers to the launch's list: ONE counter increment per wavefront (262,144 increments of one word took
+    // 650 us at the first step after a reset, where nearly every board loses)
+    const unsigned long long losers = __ballot(lost);
+    if (!lost) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)losers) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(d.count + d.parity, (unsigned int)__popcll(losers));
+    base = (unsigned int)__shfl((int)base, leader);
+    const unsigned int at = base + (unsigned int)__popcll(losers & ((1ull << lane) - 1ull));
+    d.cells[at] = (unsigned long long)s * 4ull + (unsigned long long)(a & 3);
+    d.targets[at] = target;
+}
+
+// The deferred transitions of a launch, in ONE follow-up launch of kDeferBlocks workgroups: (1) every transition finds (or
+// claims) the accumulator of its cell and adds its target; (2) the transition that claimed a cell applies the combined
+// update and frees the accumulator.  Between the phases the workgroups meet at a counter in the scratch -- they are all
+// resident (one per CU at most) -- but ONLY when something was deferred: with an empty list (boards spread over distinct
+// states: the usual case) every workgroup reads one word and leaves.
+constexpr int kDeferBlocks = 64;
+constexpr unsigned int kDeferSolo = 1024;
+__global__ __launch_bounds__(kBlock) void qtable_defer_kernel(Entry* table, Deferred d, double alpha) {
+    const unsigned int n = d.count[d.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.count[d.parity ^ 1] = 0u; d.count[2 + (d.parity ^ 1)] = 0u; }   // the next launch's list and meeting point
+    if (n == 0u) return;
+    // A short list (the steady state: a few popular states are still shared by some boards) is ONE workgroup's work -- the
+    // others leave, and the two phases are separated by a workgroup barrier; only a long list (the steps after a reset) is
+    // spread over all workgroups, which then meet at the counter (that meeting alone costs ~25 us).
+    const bool solo = n <= kDeferSolo;
+    if (solo && blockIdx.x != 0) return;
+    const unsigned int first = solo ? threadIdx.x : blockIdx.x * kBlock + threadIdx.x, stride = solo ? kBlock : gridDim.x * kBlock;
+    for (unsigned int i = first; i < n; i += stride) {
+        const unsigned long long cell = d.cells[i], tag = cell + 1ull;
+        unsigned int h = (unsigned int)mix64(cell) & (d.acc_slots - 1u);
+        int mine = -1;
+        for (;;) {                                        // acc_slots >= 2 n: a free slot always exists
+            unsigned long long cur = d.acc_key[h];
+            if (cur == 0ull) { cur = atomicCAS(d.acc_key + h, 0ull, tag); if (cur == 0ull) { mine = (int)h; break; } }
+            if (cur == tag) break;
+            h = (h + 1u) & (d.acc_slots - 1u);
+        }
+        atomicAdd(d.acc_cnt + h, 1u);
+        atomicAdd(d.acc_sum + h, d.targets[i]);
+        d.owner[i] = mine;
+    }
+    __threadfence();
+    __syncthreads();
+    if (!solo && threadIdx.x == 0) {
+        unsigned int* meet = d.count + 2 + d.parity;
+        atomicAdd(meet, 1u);
+        const long long t0 = wall_clock64();          // (100 MHz; a wait that outlasts 3 s gives up rather than hang the device)
+        while (__hip_atomic_load(meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && wall_clock64() - t0 < 300000000ll)
+            __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __threadfence();
+    for (unsigned int i = first; i < n; i += stride) {
+        const int h = d.owner[i];
+        if (h < 0) continue;
+        const unsigned long long cell = d.cells[i];
+        const unsigned int k = __hip_atomic_load(d.acc_cnt + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sum = __hip_atomic_load(d.acc_sum + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double mean = sum / (double)k;
+        double* q = &table[cell >> 2].q[cell & 3ull];
+        const double old = *q;
+        // k = 1: exactly numba.py:38-39; k > 1: the k transitions one after another, each with the mean of their targets
+        const double w = k == 1u ? alpha : 1.0 - pow(1.0 - alpha, (double)k);
+        *q = __dadd_rn(old, __dmul_rn(w, __dsub_rn(mean, old)));
+        d.acc_key[h] = 0ull; d.acc_cnt[h] = 0u; d.acc_sum[h] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void qtable_select_kernel(Entry* table, uint64_t capacity, uint64_t region_slots,
                                                               const int32_t* __restrict__ boards, int n_boards, int cells,
                                                               double epsilon, uint64_t seed, uint64_t board_id0, uint64_t step_counter,
                                                               int64_t* __restrict__ actions, int64_t* __restrict__ slots_out) {
@@ -78,55 +208,79 @@ __global__ __launch_bounds__(kBlock) void qtable_select_kernel(unsigned long lon
     if (g >= n_boards) return;
     const uint64_t key = pack_board(boards + (size_t)g * cells, cells);
     const uint64_t base = region_slots ? (uint64_t)g * region_slots : 0, slots = region_slots ? region_slots : capacity;
-    const long long s = find_or_insert(keys, base, slots, key);
+    const long long s = find_or_insert(table, base, slots, key);
     slots_out[g] = s;
     const U4 r = philox4x32(seed, board_id0 + (uint64_t)g, step_counter);
-    const double p = (double)(((uint64_t)r.x << 21) ^ (uint64_t)(r.y >> 11)) * (1.0 / 9007199254740992.0);   // 53-bit uniform
-    int a;
-    if (p < epsilon || s < 0) {
-        a = (int)__umulhi(r.z, 4u);                                      // numba.py:9-11 random.randint(0, n-1)
-    } else {
-        const double* q = values + (size_t)s * 4;
-        a = 0; double mx = q[0];
-        for (int i = 1; i < 4; ++i) if (q[i] > mx) { mx = q[i]; a = i; }   // numba.py:13-19
-    }
-    actions[g] = a;
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (s >= 0) { q[0] = table[s].q[0]; q[1] = table[s].q[1]; q[2] = table[s].q[2]; q[3] = table[s].q[3]; }
+    actions[g] = choose_action(r, epsilon, q, s >= 0);
 }
 
-__global__ __launch_bounds__(kBlock) void qtable_update_kernel(unsigned long long* keys, double* values, uint64_t capacity,
-                                                              uint64_t region_slots, const int64_t* __restrict__ slots_s,
-                                                              const int64_t* __restrict__ actions, const int32_t* __restrict__ rewards,
-                                                              const int32_t* __restrict__ next_boards, const uint8_t* __restrict__ terminal,
-                                                              int n_boards, int cells, double alpha, double gamma) {
+__global__ __launch_bounds__(kBlock) void qtable_update_kernel(Entry* table, uint64_t capacity, uint64_t region_slots,
+                                                              const int64_t* __restrict__ slots_s, const int64_t* __restrict__ actions,
+                                                              const int32_t* __restrict__ rewards, const int32_t* __restrict__ next_boards,
+                                                              const uint8_t* __restrict__ terminal, int n_boards, int cells, double alpha,
+                                                              double gamma, Deferred d) {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= n_boards) return;
     const long long s = slots_s[g];
     if (s < 0) return;
     const uint64_t base = region_slots ? (uint64_t)g * region_slots : 0, slots = region_slots ? region_slots : capacity;
     // QLearningNumba.py:28-37 touches q[next_state] even for terminal transitions (defaultdict insert)
-    const long long sn = find_or_insert(keys, base, slots, pack_board(next_boards + (size_t)g * cells, cells));
+    const long long sn = find_or_insert(table, base, slots, pack_board(next_boards + (size_t)g * cells, cells));
     double mx = 0.0;
     if (sn >= 0) {
-        const double* qn = values + (size_t)sn * 4;
-        mx = qn[0];
-        for (int i = 1; i < 4; ++i) if (qn[i] > mx) mx = qn[i];           // numba.py:28-31
+        mx = table[sn].q[0];
+        for (int i = 1; i < 4; ++i) if (table[sn].q[i] > mx) mx = table[sn].q[i];             // numba.py:28-31
     }
     const double reward = (double)rewards[g];
     const double target = terminal[g] ? reward : __dadd_rn(reward, __dmul_rn(gamma, mx));       // numba.py:33-36
-    double* cell = values + (size_t)s * 4 + (actions[g] & 3);
-    if (region_slots) {
-        const double old = *cell;
-        *cell = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));                       // numba.py:38-39
-    } else {
-        unsigned long long* raw = reinterpret_cast<unsigned long long*>(cell);
-        unsigned long long seen = *raw, assumed;
-        do {
-            assumed = seen;
-            const double old = __longlong_as_double((long long)assumed);
-            const double upd = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));
-            seen = atomicCAS(raw, assumed, (unsigned long long)__double_as_longlong(upd));
-        } while (seen != assumed);
+    apply_update(table, s, (int)(actions[g] & 3), target, alpha, region_slots == 0, d);
+}
+
+// One roll-out step of B learners in one launch: what select -> pulse_tfe_step -> update do in three, with the board in
+// registers throughout.  slots_io: in = the entry of every board's current state if a previous step found it (-2 =
+// unknown: look it up), out = the entry of the state the move led to.  Draws: the agent's Philox stream (agent_seed,
+// board, agent_step) as pulse_qtable_select, the environment's (env_seed, board, env_step) as pulse_tfe_step.
+template <int NB>
+__global__ __launch_bounds__(kBlock) void qtable_rollout_step_kernel(Entry* table, uint64_t capacity, uint64_t region_slots,
+                                                                    int32_t* __restrict__ boards, int64_t* __restrict__ total_score,
+                                                                    int n_boards, double epsilon, double alpha, double gamma,
+                                                                    uint64_t agent_seed, uint64_t agent_step, uint64_t env_seed, uint64_t env_step,
+                                                                    uint64_t board_id0, int64_t* __restrict__ actions, int32_t* __restrict__ rewards,
+                                                                    uint8_t* __restrict__ dones, int64_t* __restrict__ slots_io, Deferred d) {
+    using namespace pulse_tfe;
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n_boards) return;
+    int b[NB * NB];
+    int32_t* bp = boards + (size_t)g * NB * NB;
+#pragma unroll
+    for (int i = 0; i < NB * NB; ++i) b[i] = bp[i];
+    const uint64_t base = region_slots ? (uint64_t)g * region_slots : 0, slots = region_slots ? region_slots : capacity;
+    long long s = slots_io[g];
+    if (s == -2) s = find_or_insert(table, base, slots, pack_cells(b, NB * NB));
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (s >= 0) { q[0] = table[s].q[0]; q[1] = table[s].q[1]; q[2] = table[s].q[2]; q[3] = table[s].q[3]; }
+    const int a = choose_action(philox4x32(agent_seed, board_id0 + (uint64_t)g, agent_step), epsilon, q, s >= 0);
+    const int score = tfe_move<NB>(b, a);
+    const U4 rnd = philox4x32(env_seed, board_id0 + (uint64_t)g, env_step);
+    tfe_spawn<NB>(b, rnd.x, rnd.y);                                                     // TFE.py:182 (always)
+    const int reward = score > 0 ? 31 - __clz(score) : 0;                                // TFE.py:185-187
+    const bool over = tfe_over<NB>(b);
+#pragma unroll
+    for (int i = 0; i < NB * NB; ++i) bp[i] = b[i];
+    total_score[g] += score;
+    actions[g] = a; rewards[g] = reward; dones[g] = over;
+    const long long sn = find_or_insert(table, base, slots, pack_cells(b, NB * NB));
+    slots_io[g] = sn;
+    if (s < 0) return;                                                                  // no room for the state: acted at random, learns nothing
+    double mx = 0.0;
+    if (sn >= 0) {
+        mx = table[sn].q[0];
+        for (int i = 1; i < 4; ++i) if (table[sn].q[i] > mx) mx = table[sn].q[i];
     }
+    const double target = over ? (double)reward : __dadd_rn((double)reward, __dmul_rn(gamma, mx));
+    apply_update(table, s, a, target, alpha, region_slots == 0, d);
 }
 
 int finish_launch(const char* what) {
@@ -136,13 +290,32 @@ int finish_launch(const char* what) {
 }
 
 int check_table(const PulseQTable* q, int32_t n_boards, int32_t n) {
-    if (!q || !q->keys || !q->values) return pulse::fail(PULSE_EINVAL, "PulseQTable: null table");
+    if (!q || !q->entries) return pulse::fail(PULSE_EINVAL, "PulseQTable: null table");
+    if (((uintptr_t)q->entries & 63u) != 0) return pulse::fail(PULSE_EINVAL, "PulseQTable: entries must be 64-byte aligned");
     if (n < 3 || n > 4) return pulse::fail(PULSE_EINVAL, "PulseQTable: board side must be 3 or 4 (64-bit state key)");
     const uint64_t slots = q->region_slots ? q->region_slots : q->capacity;
     if (slots == 0 || (slots & (slots - 1))) return pulse::fail(PULSE_EINVAL, "PulseQTable: capacity / region_slots must be a power of two");
     if (q->region_slots && (uint64_t)n_boards * q->region_slots > q->capacity)
         return pulse::fail(PULSE_EINVAL, "PulseQTable: capacity < n_boards * region_slots");
     return 0;
+}
+
+// the shared table's scratch, checked and turned into the kernels' view of it
+int deferred_of(const PulseQTable* q, const PulseQTableScratch* sc, int32_t n_boards, uint64_t launch_index, Deferred* d) {
+    *d = Deferred{};
+    if (q->region_slots) return 0;                      // private regions: no race, no scratch
+    if (!sc || !sc->count || !sc->cells || !sc->targets || !sc->owner || !sc->acc_key || !sc->acc_cnt || !sc->acc_sum)
+        return pulse::fail(PULSE_EINVAL, "PulseQTable: a shared table needs its PulseQTableScratch");
+    if (sc->n < (uint32_t)n_boards || sc->acc_slots < 2u * (uint32_t)n_boards || (sc->acc_slots & (sc->acc_slots - 1u)))
+        return pulse::fail(PULSE_EINVAL, "PulseQTableScratch: need n >= n_boards and acc_slots a power of two >= 2 n_boards");
+    *d = Deferred{sc->count, reinterpret_cast<unsigned long long*>(sc->cells), sc->targets, sc->owner,
+                  reinterpret_cast<unsigned long long*>(sc->acc_key), sc->acc_cnt, sc->acc_sum, sc->acc_slots, (int)(launch_index & 1u)};
+    return 0;
+}
+void launch_deferred(Entry* table, const Deferred& d, double alpha, hipStream_t st) {
+    if (!d.count) return;
+    // few, fat workgroups: with nothing deferred (boards spread over distinct states: the usual case) each reads one word and leaves
+    hipLaunchKernelGGL(qtable_defer_kernel, dim3(kDeferBlocks), dim3(kBlock), 0, st, table, d, alpha);
 }
 
 }  // namespace
@@ -155,22 +328,48 @@ int pulse_qtable_select(const PulseQTable* q, const int32_t* boards, int32_t n_b
     if (!boards || !actions || !slots || n_boards < 0) return pulse::fail(PULSE_EINVAL, "pulse_qtable_select: null argument");
     if (n_boards == 0) return 0;
     hipLaunchKernelGGL(qtable_select_kernel, dim3((n_boards + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
-                       reinterpret_cast<unsigned long long*>(q->keys), q->values, q->capacity, q->region_slots, boards, n_boards, n * n,
+                       static_cast<Entry*>(q->entries), q->capacity, q->region_slots, boards, n_boards, n * n,
                        epsilon, seed, board_id0, step_counter, actions, slots);
     return finish_launch("pulse_qtable_select");
 }
 
-int pulse_qtable_update(const PulseQTable* q, const int64_t* slots, const int64_t* actions, const int32_t* rewards,
-                        const int32_t* next_boards, const uint8_t* terminal, int32_t n_boards, int32_t n, double alpha, double gamma,
-                        void* stream) {
+int pulse_qtable_update(const PulseQTable* q, const PulseQTableScratch* scratch, uint64_t launch_index, const int64_t* slots,
+                        const int64_t* actions, const int32_t* rewards, const int32_t* next_boards, const uint8_t* terminal,
+                        int32_t n_boards, int32_t n, double alpha, double gamma, void* stream) {
     if (int rc = check_table(q, n_boards, n)) return rc;
     if (!slots || !actions || !rewards || !next_boards || !terminal || n_boards < 0)
         return pulse::fail(PULSE_EINVAL, "pulse_qtable_update: null argument");
     if (n_boards == 0) return 0;
+    Deferred d;
+    if (int rc = deferred_of(q, scratch, n_boards, launch_index, &d)) return rc;
+    Entry* table = static_cast<Entry*>(q->entries);
     hipLaunchKernelGGL(qtable_update_kernel, dim3((n_boards + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
-                       reinterpret_cast<unsigned long long*>(q->keys), q->values, q->capacity, q->region_slots, slots, actions, rewards,
-                       next_boards, terminal, n_boards, n * n, alpha, gamma);
+                       table, q->capacity, q->region_slots, slots, actions, rewards, next_boards, terminal, n_boards, n * n, alpha, gamma, d);
+    launch_deferred(table, d, alpha, (hipStream_t)stream);
     return finish_launch("pulse_qtable_update");
+}
+
+int pulse_qtable_rollout_step(const PulseQTable* q, const PulseQTableScratch* scratch, uint64_t launch_index, int32_t* boards,
+                              int64_t* total_score, int32_t n_boards, int32_t n, double epsilon, double alpha, double gamma,
+                              uint64_t agent_seed, uint64_t agent_step, uint64_t env_seed, uint64_t env_step, uint64_t board_id0,
+                              int64_t* actions, int32_t* rewards, uint8_t* dones, int64_t* slots_io, void* stream) {
+    if (int rc = check_table(q, n_boards, n)) return rc;
+    if (!boards || !total_score || !actions || !rewards || !dones || !slots_io || n_boards < 0)
+        return pulse::fail(PULSE_EINVAL, "pulse_qtable_rollout_step: null argument");
+    if (env_step == 0) return pulse::fail(PULSE_EINVAL, "pulse_qtable_rollout_step: env_step must be >= 1 (0 is the reset draw)");
+    if (n_boards == 0) return 0;
+    Deferred d;
+    if (int rc = deferred_of(q, scratch, n_boards, launch_index, &d)) return rc;
+    Entry* table = static_cast<Entry*>(q->entries);
+    const dim3 grid((n_boards + kBlock - 1) / kBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+#define PULSE_QT_ARGS table, q->capacity, q->region_slots, boards, total_score, n_boards, epsilon, alpha, gamma, agent_seed, agent_step, env_seed, \
+                      env_step, board_id0, actions, rewards, dones, slots_io, d
+    if (n == 3) hipLaunchKernelGGL(qtable_rollout_step_kernel<3>, grid, block, 0, st, PULSE_QT_ARGS);
+    else hipLaunchKernelGGL(qtable_rollout_step_kernel<4>, grid, block, 0, st, PULSE_QT_ARGS);
+#undef PULSE_QT_ARGS
+    launch_deferred(table, d, alpha, st);
+    return finish_launch("pulse_qtable_rollout_step");
 }
 
 }  // extern "C"

@@ -231,6 +231,83 @@ def test_batched_q_learning_matches_reference_semantics_per_board():
     assert sum(len(t) for t in tables) > B * 20 and max(float(np.abs(v).max()) for t in tables for v in t.values()) > 0
 
 
+@pytest.mark.parametrize("private", [True, False], ids=["private-tables", "shared-table"])
+def test_fused_rollout_step_equals_select_step_update(private):
+    """pulse_qtable_rollout_step (select + 2048 move + update in one launch, the found s' carried to the next step) against the
+    three separate calls: same actions, boards, rewards, done flags, scores, and the same table -- bit for bit with private
+    tables (no races); with a shared table at a size where boards never meet in a state, too."""
+    from pulselib_amd.agents import QLearningBatch
+    from pulselib_amd.environments.TFE import TFEBatch
+    B, n, steps = 2048, 4, 50
+    cfg = {"ALPHA": 0.1, "GAMMA": 0.99, "EPSILON": 0.1}
+    dev = torch.device(DEV)
+    kw = dict(config=cfg, private_tables=private, slots=128 if private else 1 << 20, seed=991)
+    e1, e2 = TFEBatch(dev, B, n, seed=77), TFEBatch(dev, B, n, seed=77)
+    a1, a2 = QLearningBatch(dev, B, n, **kw), QLearningBatch(dev, B, n, **kw)
+    e1.reset(); e2.reset()
+    if not private:
+        # give every board a start state of its own (distinct tiles in the last row), so that no two boards ever update one
+        # entry in the same launch: the shared table is then race-free and must match exactly
+        for e in (e1, e2):
+            e.boards[:, 3, :] = 0
+            ids = torch.arange(B, device=dev)
+            for c in range(4):
+                e.boards[:, 3, c] = (2 ** (1 + ((ids >> (3 * c)) & 7))).to(torch.int32)
+    for s in range(steps):
+        acts = a1.get_actions(e1.boards, s).clone()
+        nb, r, d, _, _ = e1.step(acts)
+        a1.update(nb, r, d)
+        nb2, r2, d2, _, _ = a2.rollout_step(e2, s)
+        np.testing.assert_array_equal(_np(a2.actions), _np(acts), err_msg=f"step {s} actions")
+        np.testing.assert_array_equal(_np(nb2), _np(nb), err_msg=f"step {s} boards")
+        np.testing.assert_array_equal(_np(r2), _np(r), err_msg=f"step {s} rewards")
+        np.testing.assert_array_equal(_np(d2), _np(d), err_msg=f"step {s} dones")
+        np.testing.assert_array_equal(_np(e2.total_score), _np(e1.total_score))
+        if s == 20:                                   # boards changed behind the agent's back: the carried entries must be dropped
+            for e in (e1, e2):
+                e.boards[::2] = e.boards[::2].flip(1).contiguous()
+            a2.forget_states()
+    if private:
+        np.testing.assert_array_equal(_np(a2.keys), _np(a1.keys))
+        np.testing.assert_array_equal(_np(a2.values), _np(a1.values))
+    else:
+        # Boards start from distinct states, but merges can still lead two of them through one state in the same launch: there
+        # the reads of q[s'] race with another board's update of that very entry (in both forms).  All but a handful of the
+        # ~100,000 entries must agree exactly.
+        t1, t2 = a1.table(), a2.table()
+        assert set(t1) == set(t2) and len(t1) > B * 10
+        differing = sum(1 for k, v in t1.items() if not np.array_equal(t2[k], v))
+        assert differing <= len(t1) // 1000, f"{differing} of {len(t1)} entries differ"
+    assert float(_np(a1.values).max()) > 0
+
+
+def test_shared_table_combines_simultaneous_updates_of_one_entry():
+    """Many boards in the SAME state taking the SAME action in one launch (what happens right after reset): one update
+    goes through alone, the others are combined per cell -- with equal targets the result is the k + 1 updates applied one
+    after another, q0 + (1 - (1 - alpha)^(k+1)) (t - q0), whatever the order (csrc/qtable.hip)."""
+    from pulselib_amd.agents import QLearningBatch
+    B, n = 4096, 4
+    dev = torch.device(DEV)
+    agent = QLearningBatch(dev, B, n, config={"ALPHA": 0.25, "GAMMA": 0.0, "EPSILON": 0.0}, slots=1 << 12, seed=1)
+    board = torch.tensor([[2, 4, 8, 16], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 2, 0]], dtype=torch.int32, device=dev)
+    boards = board.repeat(B, 1, 1).contiguous()
+    nxt = boards.clone(); nxt[:, 1, 1] = 2
+    rewards = torch.full((B,), 3, dtype=torch.int32, device=dev)
+    term = torch.zeros(B, dtype=torch.bool, device=dev)
+    q = 0.0
+    for rnd in range(3):
+        acts = agent.get_actions(boards, rnd)
+        assert int(acts.min()) == int(acts.max())                      # greedy on equal rows: everybody takes the first maximum
+        a = int(acts[0])
+        agent.update(nxt, rewards, term)
+        q = q + (1.0 - 0.75 ** B) * (3.0 - q)                          # B transitions with target 3 (gamma = 0)
+        tab = agent.table()
+        key = [k for k, v in tab.items() if v[a] != 0.0]
+        assert len(key) == 1
+        assert abs(tab[key[0]][a] - q) < 1e-12 and all(tab[key[0]][i] == 0.0 for i in range(4) if i != a)
+    assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) == 0 and int(agent._scratch_tensors["acc_cnt"].sum()) == 0      # scratch left clean
+
+
 def test_shared_q_table_learns_and_loses_no_update():
     """Shared-table mode at config-3 size: all 262,144 boards start from states with two tiles, so thousands of
     boards update the same entries concurrently; the CAS loop must apply every one of them."""

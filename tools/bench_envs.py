@@ -62,8 +62,23 @@ def gpu_records(dev):
         a = agent.get_actions(env.boards, state["t"])
         nb, r, d, _, _ = env.step(a)
         agent.update(nb, r, d)
-    out.append(record("tfe_qlearning_rollout_step", "2048 + tabular Q-learning (select + step + update), 262,144 boards, shared table", B,
-                      timed(rollout_step, 30), "bytes: the env step only; the hash-table lookups are cache traffic"))
+    sep = timed(rollout_step, 30)
+    env.reset()
+    agent2 = QLearningBatch(dev, B, 4, slots=1 << 26, seed=0)
+    state["t"] = 0
+
+    def fused_step():
+        state["t"] += 1
+        agent2.rollout_step(env, state["t"])
+    rec = record("tfe_qlearning_rollout_step", "2048 + tabular Q-learning roll-out step, 262,144 boards, shared table of 2^26 entries", B,
+                 timed(fused_step, 30), "QLearningBatch.rollout_step: select + move + update in ONE launch (the separate calls: "
+                 f"{sep * 1e6:.1f} us); steps 6..35 after a reset, i.e. including the steps where thousands of boards share a state; "
+                 "bytes: the env step only, the hash-table lines are extra traffic")
+    for _ in range(60):
+        fused_step()
+    rec["steady_state_us_per_step"] = timed(fused_step, 30) * 1e6            # boards spread over distinct states
+    out.append(rec)
+    del agent2
     del agent, env
     torch.cuda.empty_cache()
     P = PARTICLES
