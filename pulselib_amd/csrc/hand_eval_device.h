@@ -58,12 +58,13 @@ __device__ __forceinline__ int below(int r, int a) { return r - (a < r ? 1 : 0);
 __device__ __forceinline__ int choose2(int n) { return n * (n - 1) / 2; }
 __device__ __forceinline__ int choose3(int n) { return (int)(((uint32_t)(n * (n - 1) * (n - 2)) * 43691u) >> 18); }   // /6, exact below 2^17
 
-__device__ __forceinline__ int hand_value(const HandAcc& a) {
+// `five`: the index table to read -- kFiveIndex.v in global memory, or a copy a workgroup staged in LDS
+__device__ __forceinline__ int hand_value(const HandAcc& a, const uint16_t* five_index = kFiveIndex.v) {
     const uint32_t fl = (a.suit_n + 0x3333u) & 0x8888u;                 // a suit held five times or more (at most one)
     const uint32_t all = a.c0;
     uint32_t suited = 0;
     if (fl) suited = (uint32_t)(a.suit_ranks >> (4u * (uint32_t)(low_bit(fl) & ~3))) & 0x1FFFu;
-    const int five = kFiveIndex.v[keep_top(fl ? suited : all, 5)];      // one unconditional load serves flush and high card
+    const int five = five_index[keep_top(fl ? suited : all, 5)];        // one unconditional load serves flush and high card
     if (fl) {
         const int sh = straight_top(suited);
         return sh >= 0 ? (9 << 12) | (sh - 2) : (6 << 12) | five;

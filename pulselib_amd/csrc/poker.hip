@@ -246,6 +246,14 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     // 16 A pairs -- one wavefront for A <= 4, two for A <= 8, ... -- and the wavefronts beyond skip all of it.
     // (Wavefronts of tables past the end of the batch have left; the barrier counts only those still running.)
     if (!v.pre_board) return;
+#ifdef PULSE_FIVE_INDEX_LDS
+    // experiment (profiles/README.md, r03): the evaluator's 16 KB index table staged in LDS by every workgroup
+    __shared__ uint16_t five_s[8192];
+    for (int w = threadIdx.x; w < 8192 / 8; w += kBlock) reinterpret_cast<int4*>(five_s)[w] = reinterpret_cast<const int4*>(kFiveIndex.v)[w];
+    const uint16_t* five_index = five_s;
+#else
+    const uint16_t* five_index = kFiveIndex.v;
+#endif
     __syncthreads();
     const int t_first = blockIdx.x * (kBlock / kLanes);
     const int tables_here = min(kBlock / kLanes, v.n_games - t_first);
@@ -263,11 +271,11 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         // turn = value of the 6 cards (:500), river / showdown = value of the 7 (:437-444).
         HandAcc acc;
         hand_add(acc, c0); hand_add(acc, c1); hand_add(acc, f0); hand_add(acc, f1); hand_add(acc, f2);
-        const int v5 = hand_value(acc);
+        const int v5 = hand_value(acc, five_index);
         hand_add(acc, f3);
-        const int v6 = hand_value(acc);
+        const int v6 = hand_value(acc, five_index);
         hand_add(acc, f4);
-        const int r7 = hand_value(acc);
+        const int r7 = hand_value(acc, five_index);
         const float vf = (float)hr_at_nb(v.hand_ranks, (uint32_t)v.hand_ranks_len, v5);   // :521
         const float vt = (float)v6;                                                     // :500
         float ef = __fdiv_rn(__fsub_rn(vf, 74359.0f), 749420.0f);                       // :523

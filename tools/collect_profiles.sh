@@ -1,30 +1,59 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun): rocprofv3 passes behind the numbers bench.py and profiles/ quote.
-#   tools/collect_profiles.sh <round-tag>      e.g. r02
+#   tools/collect_profiles.sh <round-tag> [parts]      e.g. r03   (parts: poker envs trainer bench rehearsal; default all)
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never mixed
 # with --stats / trace domains).  Raw output goes to gpurun_out/<tag>/, summaries to profiles/<tag>/.
-# Two workloads: 65,536 tables (BASELINE config 2, the bench default) and 1,048,576 tables (config 4's total on one GPU).
+# Poker workloads: 65,536 tables (BASELINE config 2, the bench default) and 1,048,576 tables (config 4's total on one GPU),
+# each with active_players sampled 2..10 and forced to 10.
 set -e
 T="timeout -k 10 300"      # a profiled bench takes seconds; never let one hang the box
-TAG=${1:-r02}
+TAG=${1:-r03}
+PARTS=${2:-"poker envs trainer bench rehearsal"}
 OUT=gpurun_out/$TAG
-rm -rf $OUT          # a second run into the same directory leaves two sets of CSVs per pass behind
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python bench.py --inproc --no-cpu-baseline --trainer-loop off"
-for N in 65536 1048576; do
-  S="--tables $N --steps 600 --warmup 100"
-  echo "[collect] $(date +%T) $N tables: kernel trace"; $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$N -- $B $S > $OUT/bench_trace_$N.log 2>&1
-  echo "[collect] $(date +%T) $N tables: FETCH_SIZE"; $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$N -- $B $S > $OUT/bench_fetch_$N.log 2>&1
-  echo "[collect] $(date +%T) $N tables: WRITE_SIZE"; $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$N -- $B $S > $OUT/bench_write_$N.log 2>&1
-  echo "[collect] $(date +%T) $N tables: SQ"; $T rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/sq_$N -- $B $S > $OUT/bench_sq_$N.log 2>&1
-  echo "[collect] $(date +%T) $N tables: SQ waits"; $T rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sqw_$N -- $B $S > $OUT/bench_sqw_$N.log 2>&1
-  echo "[collect] $(date +%T) $N tables: plain"; $T $B $S > $OUT/bench_plain_$N.log 2> $OUT/bench_plain_$N.err
-done
-echo "[collect] $(date +%T) calibration"; $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python tools/pmc_calibrate.py > $OUT/calib_fetch.log 2>&1
-$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python tools/pmc_calibrate.py > $OUT/calib_write.log 2>&1
-echo "[collect] $(date +%T) default bench (the driver's line)"; $T python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
-$T python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_style.log 2> $OUT/bench_driver_style.err
-echo "[collect] $(date +%T) trainer loop"; $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trainer -- python tools/bench_trainer.py --episodes 20 > $OUT/trainer_trace.log 2>&1
-$T python tools/bench_trainer.py --episodes 20 > $OUT/trainer_plain.log 2>&1
+B="python bench.py --inproc --no-cpu-baseline --trainer-loop off --other-envs off --census off --min-timed-ms 50"
+P="rocprofv3 --kernel-trace --output-format csv"
+if [[ $PARTS == *poker* ]]; then
+for N in 65536 1048576; do for A in sampled 10; do
+  S="--tables $N --steps 600 --warmup 100 --active-players $A"; K=${N}_$A
+  rm -rf $OUT/trace_$K $OUT/fetch_$K $OUT/write_$K $OUT/sq_$K $OUT/sqw_$K
+  echo "[collect] $(date +%T) $K: kernel trace"; $T $P --stats -d $OUT/trace_$K -- $B $S > $OUT/bench_trace_$K.log 2>&1
+  echo "[collect] $(date +%T) $K: FETCH_SIZE"; $T $P --pmc FETCH_SIZE -d $OUT/fetch_$K -- $B $S > $OUT/bench_fetch_$K.log 2>&1
+  echo "[collect] $(date +%T) $K: WRITE_SIZE"; $T $P --pmc WRITE_SIZE -d $OUT/write_$K -- $B $S > $OUT/bench_write_$K.log 2>&1
+  echo "[collect] $(date +%T) $K: SQ"; $T $P --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/sq_$K -- $B $S > $OUT/bench_sq_$K.log 2>&1
+  echo "[collect] $(date +%T) $K: SQ waits"; $T $P --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sqw_$K -- $B $S > $OUT/bench_sqw_$K.log 2>&1
+  echo "[collect] $(date +%T) $K: plain"; $T $B $S > $OUT/bench_plain_$K.log 2> $OUT/bench_plain_$K.err
+done; done
+echo "[collect] $(date +%T) calibration"; rm -rf $OUT/calib_fetch $OUT/calib_write
+$T $P --pmc FETCH_SIZE -d $OUT/calib_fetch -- python tools/pmc_calibrate.py > $OUT/calib_fetch.log 2>&1
+$T $P --pmc WRITE_SIZE -d $OUT/calib_write -- python tools/pmc_calibrate.py > $OUT/calib_write.log 2>&1
+fi
+if [[ $PARTS == *envs* ]]; then
+  rm -rf $OUT/envs_trace $OUT/envs_fetch $OUT/envs_write $OUT/envs_sq
+  echo "[collect] $(date +%T) other environments: kernel trace"; $T $P --stats -d $OUT/envs_trace -- python tools/bench_envs.py > $OUT/envs_trace.log 2>&1
+  echo "[collect] $(date +%T) other environments: FETCH_SIZE"; $T $P --pmc FETCH_SIZE -d $OUT/envs_fetch -- python tools/bench_envs.py > $OUT/envs_fetch.log 2>&1
+  echo "[collect] $(date +%T) other environments: WRITE_SIZE"; $T $P --pmc WRITE_SIZE -d $OUT/envs_write -- python tools/bench_envs.py > $OUT/envs_write.log 2>&1
+  echo "[collect] $(date +%T) other environments: SQ"; $T $P --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY -d $OUT/envs_sq -- python tools/bench_envs.py > $OUT/envs_sq.log 2>&1
+  echo "[collect] $(date +%T) other environments: plain"; $T python tools/bench_envs.py > $OUT/envs_lines.jsonl 2> $OUT/envs_lines.err
+  $T python tools/qtable_steps.py 262144 130 --fused > $OUT/qtable_steps_fused.jsonl 2>&1
+  $T python tools/qtable_steps.py 262144 130 > $OUT/qtable_steps_separate.jsonl 2>&1
+fi
+if [[ $PARTS == *trainer* ]]; then
+  # the bench's own trainer_loop leg (same tool, episodes and warm-up as the number in the bench line) under the kernel trace
+  rm -rf $OUT/trainer
+  echo "[collect] $(date +%T) trainer loop"; $T $P --stats -d $OUT/trainer -- python bench.py --inproc --no-cpu-baseline --trainer-loop on --trainer-tables-large 0 --other-envs off --census off --active-players sampled --steps 200 --warmup 40 --min-timed-ms 10 > $OUT/trainer_trace.log 2>&1
+  $T python bench.py --inproc --no-cpu-baseline --trainer-loop on --other-envs off --census off --active-players sampled --steps 200 --warmup 40 --min-timed-ms 10 > $OUT/trainer_plain.log 2> $OUT/trainer_plain.err
+fi
+if [[ $PARTS == *bench* ]]; then
+  echo "[collect] $(date +%T) default bench (the driver's line)"; $T python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
+  $T python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_style.log 2> $OUT/bench_driver_style.err
+fi
+if [[ $PARTS == *rehearsal* ]]; then
+  # several ranks on ONE device (gloo): what a one-GPU box can rehearse of --gpus N
+  for R in "2 host" "2 shm" "3 shm"; do set -- $R
+    echo "[collect] $(date +%T) rehearsal: $1 ranks, $2 exchange"
+    PULSE_BENCH_ONE_DEVICE=1 $T python bench.py --gpus $1 --steps 600 --warmup 100 --min-timed-ms 100 --stop-exchange $2 > $OUT/rehearsal_${1}ranks_$2.log 2> $OUT/rehearsal_${1}ranks_$2.err || echo "rehearsal $R failed"
+  done
+fi
 python tools/summarize_profiles.py $TAG
