@@ -14,6 +14,8 @@
  * the sums differently, so comparisons carry the tolerance written in the tests.
  */
 #include <math.h>
+#include <stdlib.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -93,6 +95,15 @@ int oracle_qnet_train_grads(int state_dim, int n_actions, const float* const* w,
     const uint32_t thr = (uint32_t)(drop_p * 65536.0f);
     const float scale = 1.0f / (1.0f - drop_p);
     int count = 0; double sq = 0.0;
+    /* rows are independent: each thread sums the gradients of its (static, contiguous) share of the rows into a buffer of its
+     * own, the buffers are added in thread order afterwards -- deterministic for a given thread count.  (Serial, the 70,000-row
+     * case of the GPU suite took minutes on a busy box: an OpenMP region was opened per row by the target forward below.) */
+    const int nt = omp_get_max_threads();
+    float* gbuf = (float*)calloc((size_t)nt * o, sizeof(float));
+    #pragma omp parallel reduction(+:count, sq)
+    {
+    float* grad_t = gbuf + (size_t)omp_get_thread_num() * o;
+    #pragma omp for schedule(static)
     for (int r = 0; r < n_rows; r++) {
         const float* x = states + (size_t)r * stride;
         if (row_mask && !row_mask[r]) continue;
@@ -124,8 +135,8 @@ int oracle_qnet_train_grads(int state_dim, int n_actions, const float* const* w,
         for (int u = 0; u < n_actions; u++) d[u] = (u == act) ? 2.0f * td : 0.0f;
         for (int l = 4; l >= 0; l--) {
             for (int u = 0; u < dims[l + 1]; u++) {
-                grad[off_b[l] + u] += d[u];
-                for (int k = 0; k < dims[l]; k++) grad[off_w[l] + (size_t)u * dims[l] + k] += d[u] * a[l][k];
+                grad_t[off_b[l] + u] += d[u];
+                for (int k = 0; k < dims[l]; k++) grad_t[off_w[l] + (size_t)u * dims[l] + k] += d[u] * a[l][k];
             }
             if (l == 0) break;
             for (int k = 0; k < dims[l]; k++) {
@@ -136,6 +147,10 @@ int oracle_qnet_train_grads(int state_dim, int n_actions, const float* const* w,
             for (int k = 0; k < dims[l]; k++) d[k] = dprev[k];
         }
     }
+    }
+    for (int t = 0; t < nt; t++)
+        for (size_t i = 0; i < o; i++) grad[i] += gbuf[(size_t)t * o + i];
+    free(gbuf);
     *sum_sq = (float)sq;
     return count;
 }
