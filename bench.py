@@ -164,6 +164,7 @@ class EpisodeLoop:
         extra = getattr(self.on_episode_end, "reset_options", None)
         if extra is not None and self.episode > 0:          # the ended episode's statistics ride on the reset launch
             options.update(extra(self))
+        self.rule.drain()                     # (before the reset is enqueued: nothing but the first launch's enqueue should follow it)
         self.env.reset(options=options)
         # host-expensive follow-ups of the episode that just ended (a collective's enqueue) run while the GPU resets
         after = getattr(self.on_episode_end, "after_reset", None)
@@ -171,7 +172,6 @@ class EpisodeLoop:
             after(self)
         self.episode += 1
         self.steps_in_episode = 0
-        self.rule.drain()
 
     def run_steps(self, k, timer=None, time_every=0):
         """Run exactly k counted steps (episodes roll over inside)."""
@@ -494,6 +494,11 @@ def main_rank(args):
     env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100,
                    max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=SEED, table_id0=rank * N)
     env.chunked_rollout = not args.per_step_launches
+    if one_device and world > 1:
+        # Several ranks on ONE device (rehearsal only): a paired launch waits for its host's verdict, which waits for every
+        # rank's launch to have started -- and the launches of three processes do not all fit on one GPU at once.  One
+        # check interval per launch never waits inside the kernel.  (One process per GPU: no such coupling.)
+        env.paired_launches = False
     rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world,
                            exchange=None if args.stop_exchange == "auto" else args.stop_exchange)
     actions = torch.zeros(N, dtype=torch.long, device=device)

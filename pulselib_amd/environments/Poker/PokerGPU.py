@@ -319,7 +319,11 @@ class PokerGPU(_EnvBase):
         else:       # same storage, same pointer: only the shape the attribute shows changes
             object.__setattr__(self, "equities", self._equities_store[:N * A].view(N, A))
         v = self._view(inplace=True)
-        o = _native.PokerResetOpts()
+        o = self.__dict__.get("_reset_opts")
+        if o is None:                                   # one options block per environment, refilled (its construction was a
+            o = _native.PokerResetOpts()                # tenth of the host time of a reset)
+            object.__setattr__(self, "_reset_opts", o)
+        o.stats_rewards = o.stats_out = None
         o.first = 0 if self._has_episode else 1
         o.starting_bbs, o.max_bbs = int(self.starting_bbs), int(self.max_bbs)
         o.rotation = int(options.get('rotation', rotation)) if self._has_episode else 0
