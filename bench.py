@@ -401,13 +401,15 @@ def recorded_traffic(tables, steps_per_launch, active_players):
     the newest committed summary (profiles/rNN/step_kernel_profile*.json: FETCH_SIZE / WRITE_SIZE in separate passes,
     corrected by the dword-stream calibration recorded with them) that matches this workload AND was collected from the
     kernel source this build was compiled from (sha256 over KERNEL_SOURCES recorded at collection time); otherwise None
-    with the reason.  Returns (bytes or None, source string)."""
+    with the reason.  A summary whose mean steps per launch differs by up to 1.5 from this run's (short blocks cut a few
+    launches to one check interval) is scaled by the ratio, and says so.  Returns (bytes or None, source string)."""
     want_sha = _sha_of_kernel_sources()
     best, why = None, "no profiles/r*/step_kernel_profile*.json matches this workload"
     for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile*.json")):
         try:
             d = json.loads(f.read_text())
-            if int(d.get("tables_per_launch", -1)) != tables or int(d.get("steps_per_launch", 1)) != steps_per_launch:
+            have = float(d.get("steps_per_launch_mean", d.get("steps_per_launch", 1)))
+            if int(d.get("tables_per_launch", -1)) != tables or abs(have - steps_per_launch) > 1.5:
                 continue
             if str(d.get("active_players", "sampled")) != str(active_players):
                 continue
@@ -415,7 +417,9 @@ def recorded_traffic(tables, steps_per_launch, active_players):
             if d.get("kernel_source_sha256_16") != want_sha:
                 why = f"stale: {rel} was collected from other kernel sources ({d.get('kernel_source_sha256_16')} != {want_sha}); re-run tools/collect_profiles.sh"
                 continue
-            best, why = float(d["traffic_bytes_per_launch"]), rel
+            best, why = float(d["traffic_bytes_per_launch"]) * steps_per_launch / have, rel
+            if abs(have - steps_per_launch) > 0.05:
+                why += f" (scaled from {have:.2f} to {steps_per_launch:.2f} steps per launch)"
         except Exception:
             pass
     return (best, why) if best is not None else (None, why)
@@ -428,7 +432,7 @@ def roofline_record(args, N, sum_ms, n_launches, n_steps_timed, active_players):
     steps_per_launch = n_steps_timed / n_launches
     alg = BYTES_PER_TABLE_STEP * N * steps_per_launch
     achieved = alg / kernel_s / 1e9
-    traffic, source = recorded_traffic(N, int(round(steps_per_launch)), active_players)
+    traffic, source = recorded_traffic(N, steps_per_launch, active_players)
     rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": source,
            "traffic_GBps": None if traffic is None else traffic / kernel_s / 1e9,
