@@ -498,10 +498,11 @@ def main_rank(args):
     env = PokerGPU(device=device, agents=[], n_players=10, max_players=10, n_games=N, starting_bbs=100,
                    max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=SEED, table_id0=rank * N)
     env.chunked_rollout = not args.per_step_launches
-    if one_device and world > 1:
-        # Several ranks on ONE device (rehearsal only): a paired launch waits for its host's verdict, which waits for every
-        # rank's launch to have started -- and the launches of three processes do not all fit on one GPU at once.  One
-        # check interval per launch never waits inside the kernel.  (One process per GPU: no such coupling.)
+    if one_device and world > 2:
+        # Three or more ranks on ONE device (rehearsal only): a paired launch waits for its host's verdict, which waits for
+        # every rank's launch to have started -- and the launches of three processes at this size do not all fit on one GPU
+        # at once (two do).  One check interval per launch never waits inside the kernel.  (One process per GPU: no such
+        # coupling.)
         env.paired_launches = False
     rule = LaggedDoneCount(device, N, TERMINATION_THRESHOLD, lag=0 if args.stop_rule == "sync" else 1, n_global=N * world,
                            exchange=None if args.stop_exchange == "auto" else args.stop_exchange)
