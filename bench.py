@@ -516,6 +516,7 @@ def main_rank(args):
         loop = EpisodeLoop(env, rule, actions, args.max_episode_steps, on_episode_end=stats, active_players=mode)
         if rank == 0:
             _log(f"active_players {mode}: warm-up {args.warmup} steps ...")
+        barrier()                              # the ranks start together (a rank seconds behind would stall every other rank's launches)
         loop.run_steps(args.warmup)
         torch.cuda.synchronize()
         timer.collect()

@@ -50,9 +50,10 @@ struct PolicyArgs {
     const uint32_t* carry2_partials; int carry2_n; long long* carry2_host; long long carry2_seq;
     uint32_t* wave_done_mid; int mid_step;
     const long long* verdict_host; long long* verdict_dev; long long verdict_id;
+    long long* verdict_err;                // pinned: set by a launch that gave up waiting for its verdict (the host then fails the call)
 };
 constexpr int kVerdictStride = 16;                          // long longs between the 64 copies of a relayed verdict word (one 128-byte line each)
-constexpr long long kVerdictSpinTicks = 300000000ll;      // 3 s of the 100 MHz wall clock: a launch never waits for a dead host for ever
+constexpr long long kVerdictSpinTicks = 2000000000ll;     // 20 s of the 100 MHz wall clock: a launch never waits for a dead host for ever
 struct ChunkArgs {                         // MULTI only: the odd steps' output buffers and the number of steps
     float* obs_odd;
     float* rewards_odd;
@@ -284,7 +285,11 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 for (;;) {
                     const long long w = __hip_atomic_load(pa.verdict_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((w >> 8) == pa.verdict_id) { flags = (int)(w & 0xFF); break; }
-                    if (wall_clock64() - t0 > kVerdictSpinTicks) { flags = 0x81; break; }     // error: treat as "over", run nothing
+                    if (wall_clock64() - t0 > kVerdictSpinTicks) {                             // error: run nothing, and tell the host
+                        flags = 0x81;
+                        if (pa.verdict_err) __hip_atomic_store(pa.verdict_err, pa.verdict_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(16);
                 }
             }
@@ -1041,7 +1046,7 @@ void launch_pair(const PulsePokerView& v_even, const PulsePokerView& v_odd, uint
         pa.carry_partials = pa.carry2_partials; pa.carry_n = pa.carry2_n; pa.carry_host = pa.carry2_host; pa.carry_seq = pa.carry2_seq; pa.carry2_n = 0;
     }
     pa.wave_done_mid = plan.wave_done_mid; pa.mid_step = plan.n_chunks == 2 ? chunk_steps : 0;
-    pa.verdict_host = plan.verdict_host; pa.verdict_dev = plan.verdict_dev; pa.verdict_id = plan.launch_id;
+    pa.verdict_host = plan.verdict_host; pa.verdict_dev = plan.verdict_dev; pa.verdict_id = plan.launch_id; pa.verdict_err = plan.verdict_err;
     const ChunkArgs ca{v_odd.obs, rewards_odd, n_steps};
     launch_chunk(v_even, actions, rewards_even, pa, ca, st);
 }

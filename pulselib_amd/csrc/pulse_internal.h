@@ -40,6 +40,7 @@ struct StopRulePair {
     StopRuleCarry carry[2];       // check points a - 2 and a - 1, where still unpublished
     const long long* verdict_host;
     long long* verdict_dev;
+    long long* verdict_err;       // pinned word a launch sets when it gave up waiting (the next claim fails the call)
     long long launch_id;
     long long first_check_point;  // a
     int n_chunks;                 // k

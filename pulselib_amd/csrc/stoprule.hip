@@ -223,7 +223,7 @@ struct PulseStopRule {
     PulseShm* shm; int rank, world;
     long long side_launches;              // check points that went through the side stream (sum -> all-reduce -> publish)
     // paired launches (pulse_internal.h: StopRulePair)
-    long long* verdict_host;              // [kSlots] pinned: {launch id << 8 | flags}, written by the host
+    long long* verdict_host;              // [kSlots + 1] pinned: {launch id << 8 | flags}, written by the host; the last word: a launch's "gave up" mark
     long long* verdict_dev;               // [kSlots] device: the same word, relayed by thread 0 of the launch
     long long launches;                   // paired launches issued so far (ids start at 1)
     long long verdicts_known;             // check points below this index have been read and did not end the episode ...
@@ -328,6 +328,11 @@ int pair_count(PulseStopRule* h, long long c, bool* over) {
 
 int stoprule_pair_claim(PulseStopRule* h, int n_partials, int n_chunks, StopRulePair* plan) {
     if (!plan || n_chunks < 1 || n_chunks > 2 || !stoprule_pairs_supported(h, n_partials)) return fail(PULSE_EINVAL, "stop rule: paired launch not possible with this handle");
+    if (const long long gave_up = __atomic_load_n(h->verdict_host + kSlots, __ATOMIC_ACQUIRE)) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "stop rule: paired launch %lld waited 20 s for its verdict and ran nothing (a rank of the job is gone or stalled)", gave_up);
+        return fail(PULSE_EINTERNAL, msg);
+    }
     if (h->over_known) return 1;                                       // a count read earlier already ended the episode
     const long long a = h->submitted;
     *plan = StopRulePair{};
@@ -335,6 +340,7 @@ int stoprule_pair_claim(PulseStopRule* h, int n_partials, int n_chunks, StopRule
     plan->launch_id = ++h->launches;
     plan->verdict_host = h->verdict_host + (plan->launch_id % kSlots);
     plan->verdict_dev = h->verdict_dev + (plan->launch_id % kSlots) * kVerdictCopies * kVerdictStride;
+    plan->verdict_err = h->verdict_host + kSlots;
     uint32_t* first = h->partials_dev + (size_t)(a % kSlots) * h->max_partials;
     uint32_t* second = h->partials_dev + (size_t)((a + 1) % kSlots) * h->max_partials;
     plan->wave_done_mid = n_chunks == 2 ? first : nullptr;
@@ -390,7 +396,7 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->partials_dev), (size_t)kSlots * h->max_partials * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->pair_dev), kSlots * 2 * sizeof(long long));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->host), kSlots * sizeof(Published), hipHostMallocCoherent | hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->verdict_host), kSlots * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->verdict_host), (kSlots + 1) * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->verdict_dev), kSlots * kVerdictCopies * kVerdictStride * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(h->verdict_dev, 0, kSlots * kVerdictCopies * kVerdictStride * sizeof(long long));
     if (e == hipSuccess && h->mode == kModeRccl) {
@@ -408,7 +414,7 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
         return code;
     }
     std::memset(h->host, 0, kSlots * sizeof(Published));
-    std::memset(h->verdict_host, 0, kSlots * sizeof(long long));
+    std::memset(h->verdict_host, 0, (kSlots + 1) * sizeof(long long));
     if (h->mode == kModeShm) {
         void* shm = nullptr;
         if (int rc = pulse_shm_create(shm_name, rank, world, &shm)) { (void)pulse_stoprule_destroy(h); return rc; }

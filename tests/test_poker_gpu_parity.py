@@ -782,6 +782,36 @@ def test_bench_gpu_leg_and_cpu_baseline_play_the_same_episodes():
     rule.close()
 
 
+def test_tables_beyond_5_6_million_in_one_view_address_their_own_cache_rows():
+    """A view may hold up to 2^24 tables.  The evaluation cache's rows [N, 3, P] were addressed with a 24-bit multiply of
+    (table * 3), which leaves 24 bits above table 5,592,405: those tables silently read ANOTHER table's equities (in bounds, so
+    nothing faults).  5,700,000 tables in one environment against the last 65,536 of them as an environment of their own
+    (global table ids): state, observations, equities and rewards of that tail must agree after chunk and single-step launches."""
+    N, tail = 5_700_000, 65536
+    kw = dict(n_players=10, max_players=10, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=77)
+    big = _gpu_env(n_games=N, table_id0=0, **kw)
+    small = _gpu_env(n_games=tail, table_id0=N - tail, **kw)
+    types = [1, 3, 2, 2, 4, 3, 1, 4, 5, 3]
+    a_big = torch.zeros(N, dtype=torch.long, device=DEV)
+    a_small = torch.zeros(tail, dtype=torch.long, device=DEV)
+    for env in (big, small):
+        env.reset(options={"active_players": 10})
+    np.testing.assert_array_equal(to_np(big.decks[N - tail:]), to_np(small.decks))
+    gstep = 0
+    for n in (10, 1, 5, 1, 10):                      # chunk launches (two lanes, slim image for the big one) and single steps (four lanes)
+        ob, rb, _, _, _ = big.rollout(types, a_big, n, gstep)
+        os_, rs, _, _, _ = small.rollout(types, a_small, n, gstep)
+        gstep += n
+        for name in INT_KEYS + ("equities",):
+            np.testing.assert_array_equal(to_np(getattr(big, name)[N - tail:]), to_np(getattr(small, name)), err_msg=f"after {gstep} steps: {name}")
+        np.testing.assert_array_equal(to_np(ob[N - tail:]), to_np(os_), err_msg=f"after {gstep} steps: obs")
+        np.testing.assert_array_equal(to_np(rb[N - tail:]), to_np(rs), err_msg=f"after {gstep} steps: rewards")
+        np.testing.assert_array_equal(to_np(a_big[N - tail:]), to_np(a_small))
+    assert float(small.equities.std()) > 0.05 and 0.1 < float(small.is_done.float().mean()) < 1.0      # streets were dealt, equities are not the 0.5 fill
+    del big
+    torch.cuda.empty_cache()
+
+
 def test_native_stop_rule_fixed_lag_counts_and_drains():
     """pulselib_amd.stoprule.LaggedDoneCount (pulse_stoprule_*): the rule of trainGPU.py:27-33 -- more than 80 % of the
     tables done -- decided on the check point submitted `lag` check points before the newest one (a FIXED lag: the
