@@ -66,7 +66,7 @@ class QNetTrain(C.Structure):
     _fields_ = [("net", QNet), ("target", QNet)] + [(n, C.c_void_p) for n in (
         "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report", "partials")] + [(n, C.c_float) for n in (
             "lr", "weight_decay", "beta1", "beta2", "eps", "max_grad_norm", "gamma", "dropout_p")] + [
-        ("update_freq", C.c_int32), ("max_blocks", C.c_int32)]
+        ("update_freq", C.c_int32), ("max_blocks", C.c_int32), ("select_scratch", C.c_void_p), ("select_words", C.c_int64)]
 
 
 class QTable(C.Structure):

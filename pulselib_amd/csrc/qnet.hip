@@ -33,6 +33,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef PULSE_STAMPS
 #define PULSE_STAMPS 0
 #endif
+// Ablations for the timeline tools (diagnostic builds only; results are wrong): -DPULSE_QABL=1 no MFMAs, 2 no GELU math,
+// 4 no dropout draws (bit mask).
+#ifndef PULSE_QABL
+#define PULSE_QABL 0
+#endif
 #if PULSE_STAMPS
 __device__ unsigned long long* g_qstamp_buf = nullptr;
 #define QSTAMP(i) do { if (threadIdx.x == 0 && g_qstamp_buf) { __builtin_amdgcn_sched_barrier(0); \
@@ -47,8 +52,8 @@ __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // one v_mad_u64_u32 each
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -236,6 +241,7 @@ struct CoopLds {                 // offsets in floats into the dynamic LDS block
                          Da = G4 + 32 * kLd, Db = Da + 128 * kLd, EndTrain = Db + 128 * kLd;
 };
 constexpr size_t kActLdsBytes = (size_t)CoopLds::EndEval * sizeof(float);
+constexpr int kActWin = 128;
 constexpr size_t kTrainLdsBytes = (size_t)CoopLds::EndTrain * sizeof(float);
 
 // GELU and its derivative for the cooperative kernels, sharing one exponential: with e = exp(-x^2 / 2),
@@ -245,13 +251,35 @@ constexpr size_t kTrainLdsBytes = (size_t)CoopLds::EndTrain * sizeof(float);
 // of mixed arguments) was 60 % of the training kernel.  Differences to torch's erff-based GELU stay at 1e-7 |x|.
 __device__ __forceinline__ void gelu_pair(float x, float& y, float& dy) {
     const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float e = __expf(-0.5f * x * x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);          // exp(-x^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));                 // 1 ulp: below the formula's own error
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     const float erf_abs = 1.0f - poly * e;
-    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    const float cdf = fmaf(copysignf(erf_abs, x), 0.5f, 0.5f);
     y = x * cdf;
-    dy = cdf + x * 0.39894228040143267794f * e;
+    dy = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
+// The same on two values at once: the multiplies and fused multiply-adds are the packed instructions (v_pk_mul_f32 /
+// v_pk_fma_f32, two lanes' worth of fp32 per issue slot); only exp2, rcp and the two sign operations stay per value.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_pair2(f32x2 x, f32x2& y, f32x2& dy) {
+    f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 den = fma2(ax, splat2(0.3275911f * 0.70710678118654752440f), splat2(1.0f));
+    const f32x2 ea = (x * x) * splat2(-0.72134752044448170368f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 p = fma2(t, splat2(1.061405429f), splat2(-1.453152027f));
+    p = fma2(t, p, splat2(1.421413741f));
+    p = fma2(t, p, splat2(-0.284496736f));
+    p = fma2(t, p, splat2(0.254829592f));
+    const f32x2 erf_abs = fma2(t * p, -e, splat2(1.0f));
+    const f32x2 s = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+    const f32x2 cdf = fma2(s, splat2(0.5f), splat2(0.5f));
+    y = x * cdf;
+    dy = fma2(x * splat2(0.39894228040143267794f), e, cdf);
 }
 
 // store an accumulator tile as [unit0 + row-of-tile][column]
@@ -263,15 +291,27 @@ __device__ __forceinline__ void store_t(float* __restrict__ S, int unit0, const 
 // keep-mask bits of the 16 accumulator rows of tile `tile` (units 32*tile + rho(r) + 4h) for table `gid`:
 // unit u drops when the 16-bit uniform (call u / 8, word (u % 8) / 2, half u % 2) is below drop_p * 65536.
 __device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t gid, uint64_t step, int tile, int h, uint32_t thr) {
+    // The two lanes of a column (h = 0, 1) need the same four calls, one half of each call's words: lane h makes calls
+    // 2h and 2h + 1 and hands the partner its half of them through the lane pair.
+    if (PULSE_QABL & 4) return 0xFFFFu;
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int blk = 2 * h + i;                            // units 32*tile + 8*blk + 4h' + {0,1,2,3} = registers 4*blk + j of half h'
+        const U4 w = philox4x32(seed ^ 0xD50F0D50F0ull, gid, step * 32 + (uint64_t)(4 * tile + blk));
+        const uint32_t mine_lo = h ? w.z : w.x, mine_hi = h ? w.w : w.y, send_lo = h ? w.x : w.z, send_hi = h ? w.y : w.w;
+        const uint32_t got_lo = (uint32_t)__shfl_xor((int)send_lo, 32), got_hi = (uint32_t)__shfl_xor((int)send_hi, 32);
+        // this lane's call blk = 2h + i; the partner's = 2(1 - h) + i
+        lo[i] = h ? got_lo : mine_lo; hi[i] = h ? got_hi : mine_hi;                  // calls 0, 1
+        lo[2 + i] = h ? mine_lo : got_lo; hi[2 + i] = h ? mine_hi : got_hi;          // calls 2, 3
+    }
     uint32_t bits = 0;
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {                       // units 32*tile + 8*blk + 4h + {0,1,2,3} = registers 4*blk + j
-        const U4 w = philox4x32(seed ^ 0xD50F0D50F0ull, gid, step * 32 + (uint64_t)(4 * tile + blk));
-        const uint32_t lo = h ? w.z : w.x, hi = h ? w.w : w.y;
-        bits |= (uint32_t)((lo & 0xFFFFu) >= thr) << (4 * blk + 0);
-        bits |= (uint32_t)((lo >> 16) >= thr) << (4 * blk + 1);
-        bits |= (uint32_t)((hi & 0xFFFFu) >= thr) << (4 * blk + 2);
-        bits |= (uint32_t)((hi >> 16) >= thr) << (4 * blk + 3);
+    for (int blk = 0; blk < 4; ++blk) {
+        bits |= (uint32_t)((lo[blk] & 0xFFFFu) >= thr) << (4 * blk + 0);
+        bits |= (uint32_t)((lo[blk] >> 16) >= thr) << (4 * blk + 1);
+        bits |= (uint32_t)((hi[blk] & 0xFFFFu) >= thr) << (4 * blk + 2);
+        bits |= (uint32_t)((hi[blk] >> 16) >= thr) << (4 * blk + 3);
     }
     return bits;
 }
@@ -280,10 +320,8 @@ __device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t gi
 // of the call are issued before the first MFMA (the loop is otherwise one L2 round trip per four MFMAs).  VEC: W rows are
 // 16-byte aligned and K % 8 == 0 (a float4 feeds four MFMAs); else scalar loads guarded by k < K.
 template <bool VEC, int NK8>
-__device__ __forceinline__ f32x16 dense_lds(const float* __restrict__ w, int K, int out_row, int c, int h, const float* __restrict__ S,
-                                            int k0, int k1) {
+__device__ __forceinline__ void load_w(float (&wa)[NK8][4], const float* __restrict__ w, int K, int out_row, int h, int k0, int k1) {
     const float* wr = w + (size_t)out_row * K;
-    float wa[NK8][4];
 #pragma unroll
     for (int i = 0; i < NK8; ++i) {
         const int k = k0 + 8 * i + 4 * h;
@@ -296,16 +334,65 @@ __device__ __forceinline__ f32x16 dense_lds(const float* __restrict__ w, int K, 
             for (int j = 0; j < 4; ++j) wa[i][j] = (k0 + 8 * i < k1 && k + j < K) ? wr[k + j] : 0.0f;
         }
     }
+}
+// The B operands (one LDS word per MFMA) are read 16 at a time, one chunk ahead of the chunk being multiplied: left to
+// itself the compiler reads two, waits, multiplies, and every pair of MFMAs then pays an LDS round trip.  All NK8 steps
+// of 8 k from k0 are taken: steps past a layer's inputs multiply zero weights (load_w / load_layer) with rows of S that
+// exist and are finite (layer 1: Xs is zero-filled up to 64 inputs).
+template <int NK8>
+__device__ __forceinline__ f32x16 mfma_w(const float (&wa)[NK8][4], int c, int h, const float* __restrict__ S, int k0) {
     f32x16 acc = zero16();
+    constexpr int CH = NK8 < 4 ? NK8 : 4, NCH = (NK8 + CH - 1) / CH;
+    float bv[2][CH][4];
+    auto read = [&](int ch) {
 #pragma unroll
-    for (int i = 0; i < NK8; ++i) {
-        const int k = k0 + 8 * i + 4 * h;
-        if (k0 + 8 * i < k1) {
+        for (int i = 0; i < CH; ++i) {
+            const int k = k0 + 8 * (ch * CH + i) + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][j], S[(k + j) * kLd + c], acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) bv[ch & 1][i][j] = (ch * CH + i < NK8) ? S[(k + j) * kLd + c] : 0.0f;
         }
+    };
+    read(0);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) read(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (ch * CH + i < NK8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (PULSE_QABL & 1) acc[j] += wa[ch * CH + i < NK8 ? ch * CH + i : 0][j] * bv[ch & 1][i][j];
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ch * CH + i < NK8 ? ch * CH + i : 0][j], bv[ch & 1][i][j], acc, 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
+}
+template <bool VEC, int NK8>
+__device__ __forceinline__ f32x16 dense_lds(const float* __restrict__ w, int K, int out_row, int c, int h, const float* __restrict__ S,
+                                            int k0, int k1) {
+    float wa[NK8][4];
+    load_w<VEC, NK8>(wa, w, K, out_row, h, k0, k1);
+    return mfma_w<NK8>(wa, c, h, S, k0);
+}
+
+// Workgroup barrier for waves that talk through LDS only: waits for this wave's LDS traffic, not for its global loads
+// (__syncthreads' release fence is s_waitcnt vmcnt(0) too, which puts every weight load issued ahead of a barrier back on
+// the critical path).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// This lane's A operands of layer `layer` (0..4): W[out_row][k0 + 8 i + 4 h + j] from the torch layout.
+// (Tried and dropped: reading them from a transposed copy [in][out] kept in step by the AdamW launch, so that a wavefront's
+// load is two runs of 32 consecutive floats instead of 64 rows x 16 bytes -- no faster, the kernels are not bound by how
+// the weights arrive)
+template <bool VEC, int NK8>
+__device__ __forceinline__ void load_layer(float (&wa)[NK8][4], const PulseQNet& n, int layer, int out_row, int h, int k0, int k1) {
+    const float* w = layer == 0 ? n.w1 : layer == 1 ? n.w2 : layer == 2 ? n.w3 : layer == 3 ? n.w4 : n.w5;
+    const int n_in = layer == 0 ? n.state_dim : layer == 1 ? 128 : layer == 2 ? 128 : layer == 3 ? 64 : 32;
+    load_w<VEC, NK8>(wa, w, n_in, out_row, h, k0, k1);
 }
 
 // hidden layer epilogue: z = acc + bias -> a = gelu(z) * m to As; TRAIN also g = gelu'(z) * m to Gs (m = dropout keep * scale)
@@ -313,14 +400,15 @@ template <bool TRAIN>
 __device__ __forceinline__ void coop_epilogue(const f32x16& acc, const float* __restrict__ bias, int unit0, int c, int h, uint32_t keep,
                                               float scale, float* __restrict__ As, float* __restrict__ Gs) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; r += 2) {                             // registers r, r + 1 are units u, u + 1
         const int u = unit0 + rho(r) + 4 * h;
-        const float z = acc[r] + bias[u];
-        const float m = ((keep >> r) & 1u) ? scale : 0.0f;
-        float y, dy;
-        gelu_pair(z, y, dy);
-        As[u * kLd + c] = y * m;
-        if (TRAIN) Gs[u * kLd + c] = dy * m;
+        const f32x2 z = {acc[r] + bias[u], acc[r + 1] + bias[u + 1]};
+        const f32x2 m = {((keep >> r) & 1u) ? scale : 0.0f, ((keep >> (r + 1)) & 1u) ? scale : 0.0f};
+        f32x2 y, dy;
+        if (PULSE_QABL & 2) { y = z; dy = z; } else gelu_pair2(z, y, dy);
+        y = y * m;
+        As[u * kLd + c] = y.x; As[(u + 1) * kLd + c] = y.y;
+        if (TRAIN) { dy = dy * m; Gs[u * kLd + c] = dy.x; Gs[(u + 1) * kLd + c] = dy.y; }
     }
 }
 
@@ -335,61 +423,85 @@ __device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const fl
     }
 }
 
-// The network on the 32 rows in Xs.  Returns the Q tile in wavefront 0 (other wavefronts: unspecified).  Leaves
-// a_1..a_4 (and g_1..g_4 when TRAIN) in LDS; ends on a barrier-free state: callers barrier before reusing LDS.
-template <bool TRAIN, bool VEC>
-__device__ __forceinline__ f32x16 coop_forward(const PulseQNet& n, float* __restrict__ lds, int wv, int c, int h, uint64_t seed,
-                                               uint64_t gid, uint64_t step, uint32_t thr, float scale) {
+// the five bias vectors -> Bs (b1 @0, b2 @128, b3 @256, b4 @320, b5 @352; 384 floats), all threads of the workgroup
+__device__ __forceinline__ void stage_biases(float* __restrict__ Bs, const PulseQNet& n) {
+    const float* src[5] = {n.b1, n.b2, n.b3, n.b4, n.b5};
+    const int at[6] = {0, 128, 256, 320, 352, 384}, len[5] = {128, 128, 64, 32, n.n_actions};
+    for (int i = threadIdx.x; i < 384; i += blockDim.x) {
+        float v = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) if (i >= at[l] && i < at[l] + len[l]) v = src[l][i - at[l]];
+        Bs[i] = v;
+    }
+}
+
+// The network (eval mode) on the 32 rows in Xs; layer 1's weights in w1r (loaded by the caller, before it gathered the
+// rows), biases in Bs.  Every layer issues the NEXT layer's weight loads behind its own MFMAs -- they land during its
+// epilogue -- and the barriers between the layers do not wait for them (lds_barrier): a layer never waits for L2.  Returns the Q tile in wavefront 0 (other
+// wavefronts: unspecified).  Ends on a barrier-free state: callers barrier before reusing LDS.
+template <int NK1>
+__device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], const PulseQNet& n, float* __restrict__ lds,
+                                                    const float* __restrict__ Bs, int wv, int c, int h) {
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
     float* A4 = lds + CoopLds::A4; float* P = lds + CoopLds::P;
-    float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
-    const int lane = c + 32 * h, K1 = n.state_dim, K1r = (K1 + 7) & ~7;
-    __syncthreads();                                                          // Xs complete
+    const int lane = c + 32 * h, A = n.n_actions;
+    const int ot = wv & 1, half = wv >> 1;
+    lds_barrier();                                                            // Xs complete
+    QSTAMP(2);
+    float w2r[16][4];
     {   // layer 1: wavefront wv -> units [32wv, +32)
-        const f32x16 acc = dense_lds<VEC, 8>(n.w1, K1, 32 * wv + c, c, h, Xs, 0, K1r);
-        coop_epilogue<TRAIN>(acc, n.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, G1);
+        const f32x16 acc = mfma_w<NK1>(w1r, c, h, Xs, 0);
+        load_layer<true, 16>(w2r, n, 1, 32 * wv + c, h, 0, 128);
+        coop_epilogue<false>(acc, Bs, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, nullptr);
     }
-    __syncthreads();
-    {   // layer 2 (+ Dropout, Player.py:194)
-        const f32x16 acc = dense_lds<true, 16>(n.w2, 128, 32 * wv + c, c, h, A1, 0, 128);
-        const uint32_t keep = TRAIN ? dropout_keep_bits(seed, gid, step, wv, h, thr) : 0xFFFFu;
-        coop_epilogue<TRAIN>(acc, n.b2, 32 * wv, c, h, keep, TRAIN ? scale : 1.0f, A2, G2);
+    lds_barrier();
+    QSTAMP(3);
+    float w3r[8][4];
+    {   // layer 2
+        const f32x16 acc = mfma_w<16>(w2r, c, h, A1, 0);
+        load_layer<true, 8>(w3r, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
+        coop_epilogue<false>(acc, Bs + 128, 32 * wv, c, h, 0xFFFFu, 1.0f, A2, nullptr);
     }
-    __syncthreads();
-    {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197)
-        const int ot = wv & 1, half = wv >> 1;
-        f32x16 acc = dense_lds<true, 8>(n.w3, 128, 32 * ot + c, c, h, A2, 64 * half, 64 * half + 64);
+    lds_barrier();
+    QSTAMP(4);
+    float w4r[2][4];
+    load_layer<true, 2>(w4r, n, 3, c, h, 16 * wv, 16 * wv + 16);
+    {   // layer 3: 2 output tiles x 2 halves of k
+        f32x16 acc = mfma_w<8>(w3r, c, h, A2, 64 * half);
         if (half == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[(ot * 16 + r) * 64 + lane] = acc[r];
         }
-        __syncthreads();
+        lds_barrier();
         if (half == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += P[(ot * 16 + r) * 64 + lane];
-            const uint32_t keep = TRAIN ? dropout_keep_bits(seed, gid, step, 4 + ot, h, thr) : 0xFFFFu;
-            coop_epilogue<TRAIN>(acc, n.b3, 32 * ot, c, h, keep, TRAIN ? scale : 1.0f, A3, G3);
+            coop_epilogue<false>(acc, Bs + 256, 32 * ot, c, h, 0xFFFFu, 1.0f, A3, nullptr);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    QSTAMP(5);
+    float w5r[4][4];
+    load_layer<true, 4>(w5r, n, 4, min(c, A - 1), h, 0, wv == 0 ? 32 : 0);
     {   // layer 4: one output tile, k in quarters
-        f32x16 acc = dense_lds<true, 2>(n.w4, 64, c, c, h, A3, 16 * wv, 16 * wv + 16);
+        f32x16 acc = mfma_w<2>(w4r, c, h, A3, 16 * wv);
         if (wv > 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[((wv - 1) * 16 + r) * 64 + lane] = acc[r];
         }
-        __syncthreads();
+        lds_barrier();
         if (wv == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += (P[r * 64 + lane] + P[(16 + r) * 64 + lane]) + P[(32 + r) * 64 + lane];
-            coop_epilogue<TRAIN>(acc, n.b4, 0, c, h, 0xFFFFu, 1.0f, A4, G4);
+            coop_epilogue<false>(acc, Bs + 320, 0, c, h, 0xFFFFu, 1.0f, A4, nullptr);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    QSTAMP(6);
     f32x16 qv = zero16();
     if (wv == 0) {
-        qv = dense_lds<true, 4>(n.w5, 32, min(c, n.n_actions - 1), c, h, A4, 0, 32);
-        bias_act<false>(qv, n.b5, 0, n.n_actions, h);
+        qv = mfma_w<4>(w5r, c, h, A4, 0);
+        bias_act<false>(qv, Bs + 352, 0, A, h);
     }
     return qv;
 }
@@ -397,41 +509,52 @@ __device__ __forceinline__ f32x16 coop_forward(const PulseQNet& n, float* __rest
 // Training: the target network on s' (eval) and the network on s (train mode) taken through the layers TOGETHER -- every
 // stage issues both networks' MFMAs and epilogues between one pair of barriers, so the two forwards cost 7 barrier
 // phases instead of 14.  The target's activations borrow the backward pass's delta buffers (free until then):
-// x' and a'_2, a'_4 in Db, a'_1 and a'_3 in Da.  q_tgt / q come back in wavefront 0.
-template <bool VEC>
-__device__ __forceinline__ void coop_forward_pair(const PulseQNet& nt, const PulseQNet& n, float* __restrict__ lds, int wv, int c, int h,
-                                                  uint64_t seed, uint64_t gid, uint64_t step, uint32_t thr, float scale, f32x16& q_tgt,
-                                                  f32x16& q) {
+// x' and a'_2, a'_4 in Db, a'_1 and a'_3 in Da.  q_tgt / q come back in wavefront 0.  Layer 1's weights (w1t, w1c) are
+// loaded by the caller ahead of its row gather; every layer issues the next layer's weight loads behind its MFMAs and the
+// barriers in here wait for LDS only, so those loads land during the epilogues.  Biases: global (L2) reads.
+template <bool VEC, int NK1>
+__device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], const float (&w1c)[NK1][4], const PulseQNet& nt, const PulseQNet& n,
+                                                  float* __restrict__ lds, int wv, int c, int h, uint64_t seed, uint64_t gid, uint64_t step,
+                                                  uint32_t thr, float scale, f32x16& q_tgt, f32x16& q) {
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
     float* A4 = lds + CoopLds::A4; float* P = lds + CoopLds::P; float* P2 = P + 3 * 16 * 64;
     float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
     float* Xn = lds + CoopLds::Db; float* T1 = lds + CoopLds::Da; float* T2 = lds + CoopLds::Db; float* T3 = lds + CoopLds::Da;
     float* T4 = lds + CoopLds::Db;
-    const int lane = c + 32 * h, K1 = n.state_dim, K1r = (K1 + 7) & ~7;
-    __syncthreads();                                                          // Xs, Xn complete
+    const int lane = c + 32 * h;
+    const int ot = wv & 1, half = wv >> 1;
+    lds_barrier();                                                            // Xs, Xn complete
+    float w2t[16][4], w2c[16][4];
     {   // layer 1
-        const f32x16 at = dense_lds<VEC, 8>(nt.w1, K1, 32 * wv + c, c, h, Xn, 0, K1r);
-        const f32x16 ac = dense_lds<VEC, 8>(n.w1, K1, 32 * wv + c, c, h, Xs, 0, K1r);
+        const f32x16 at = mfma_w<NK1>(w1t, c, h, Xn, 0);
+        const f32x16 ac = mfma_w<NK1>(w1c, c, h, Xs, 0);
+        load_layer<true, 16>(w2t, nt, 1, 32 * wv + c, h, 0, 128);
+        load_layer<true, 16>(w2c, n, 1, 32 * wv + c, h, 0, 128);
         coop_epilogue<false>(at, nt.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, T1, nullptr);
         coop_epilogue<true>(ac, n.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, G1);
     }
-    __syncthreads();
+    lds_barrier();
+    float w3t[8][4], w3c[8][4];
     {   // layer 2 (+ Dropout on the training side, Player.py:194)
-        const f32x16 at = dense_lds<true, 16>(nt.w2, 128, 32 * wv + c, c, h, T1, 0, 128);
-        const f32x16 ac = dense_lds<true, 16>(n.w2, 128, 32 * wv + c, c, h, A1, 0, 128);
+        const f32x16 at = mfma_w<16>(w2t, c, h, T1, 0);
+        const f32x16 ac = mfma_w<16>(w2c, c, h, A1, 0);
+        load_layer<true, 8>(w3t, nt, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
+        load_layer<true, 8>(w3c, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
         coop_epilogue<false>(at, nt.b2, 32 * wv, c, h, 0xFFFFu, 1.0f, T2, nullptr);
         coop_epilogue<true>(ac, n.b2, 32 * wv, c, h, dropout_keep_bits(seed, gid, step, wv, h, thr), scale, A2, G2);
     }
-    __syncthreads();
+    lds_barrier();
+    float w4t[2][4], w4c[2][4];
     {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197)
-        const int ot = wv & 1, half = wv >> 1;
-        f32x16 at = dense_lds<true, 8>(nt.w3, 128, 32 * ot + c, c, h, T2, 64 * half, 64 * half + 64);
-        f32x16 ac = dense_lds<true, 8>(n.w3, 128, 32 * ot + c, c, h, A2, 64 * half, 64 * half + 64);
+        f32x16 at = mfma_w<8>(w3t, c, h, T2, 64 * half);
+        f32x16 ac = mfma_w<8>(w3c, c, h, A2, 64 * half);
+        load_layer<true, 2>(w4t, nt, 3, c, h, 16 * wv, 16 * wv + 16);
+        load_layer<true, 2>(w4c, n, 3, c, h, 16 * wv, 16 * wv + 16);
         if (half == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { P[(ot * 16 + r) * 64 + lane] = at[r]; P2[(ot * 16 + r) * 64 + lane] = ac[r]; }
         }
-        __syncthreads();
+        lds_barrier();
         if (half == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { at[r] += P[(ot * 16 + r) * 64 + lane]; ac[r] += P2[(ot * 16 + r) * 64 + lane]; }
@@ -439,15 +562,18 @@ __device__ __forceinline__ void coop_forward_pair(const PulseQNet& nt, const Pul
             coop_epilogue<true>(ac, n.b3, 32 * ot, c, h, dropout_keep_bits(seed, gid, step, 4 + ot, h, thr), scale, A3, G3);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    float w5t[4][4], w5c[4][4];
     {   // layer 4: one output tile, k in quarters
-        f32x16 at = dense_lds<true, 2>(nt.w4, 64, c, c, h, T3, 16 * wv, 16 * wv + 16);
-        f32x16 ac = dense_lds<true, 2>(n.w4, 64, c, c, h, A3, 16 * wv, 16 * wv + 16);
+        f32x16 at = mfma_w<2>(w4t, c, h, T3, 16 * wv);
+        f32x16 ac = mfma_w<2>(w4c, c, h, A3, 16 * wv);
+        load_layer<true, 4>(w5t, nt, 4, min(c, n.n_actions - 1), h, 0, wv == 0 ? 32 : 0);
+        load_layer<true, 4>(w5c, n, 4, min(c, n.n_actions - 1), h, 0, wv == 0 ? 32 : 0);
         if (wv > 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { P[((wv - 1) * 16 + r) * 64 + lane] = at[r]; P2[((wv - 1) * 16 + r) * 64 + lane] = ac[r]; }
         }
-        __syncthreads();
+        lds_barrier();
         if (wv == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -458,12 +584,12 @@ __device__ __forceinline__ void coop_forward_pair(const PulseQNet& nt, const Pul
             coop_epilogue<true>(ac, n.b4, 0, c, h, 0xFFFFu, 1.0f, A4, G4);
         }
     }
-    __syncthreads();
+    lds_barrier();
     q_tgt = zero16(); q = zero16();
     if (wv == 0) {
-        q_tgt = dense_lds<true, 4>(nt.w5, 32, min(c, n.n_actions - 1), c, h, T4, 0, 32);
+        q_tgt = mfma_w<4>(w5t, c, h, T4, 0);
         bias_act<false>(q_tgt, nt.b5, 0, n.n_actions, h);
-        q = dense_lds<true, 4>(n.w5, 32, min(c, n.n_actions - 1), c, h, A4, 0, 32);
+        q = mfma_w<4>(w5c, c, h, A4, 0);
         bias_act<false>(q, n.b5, 0, n.n_actions, h);
     }
 }
@@ -485,22 +611,33 @@ __device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, i
 }
 
 // ---- masked action selection, cooperative (pulse_qnet_act with seat_idx) ------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
+// WIN candidate rows per workgroup: 128 -- two workgroups fit a CU's LDS and overlap each other's barrier phases; a sixth
+// of the candidates being the learner's, a window is one tile (256 candidates were a full tile plus a third of one).
+// NK1: steps of 8 inputs in layer 1 (5 for the 40-column observation: 12 registers less than the general 8).
+template <bool VEC, int WIN, int NK1>
+__global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
     extern __shared__ float lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    const bool sel = row < a.n_rows && a.seat_idx[row] == a.q_seat;
-    if (a.row_mask_out && row < a.n_rows)            // the trainer's `q_mask & ~terminated` (trainGPU.py:85) rides along
+    const int row = blockIdx.x * WIN + threadIdx.x;
+    const bool cand = threadIdx.x < WIN && row < a.n_rows;
+    const bool sel = cand && a.seat_idx[row] == a.q_seat;
+    if (a.row_mask_out && cand)                      // the trainer's `q_mask & ~terminated` (trainGPU.py:85) rides along
         a.row_mask_out[row] = (sel && !(a.terminated && a.terminated[row])) ? 1 : 0;
+    QSTAMP(0);
+    const int K1 = a.net.state_dim, K1r = (K1 + 7) & ~7;
+    float w1r[NK1][4];
+    load_layer<VEC, NK1>(w1r, a.net, 0, 32 * wv + c, h, 0, K1r);           // in flight during the compaction
+    float* Bs = lds + CoopLds::P + 3 * 16 * 64;                             // the second network's half of P: free in this kernel
+    stage_biases(Bs, a.net);
     const int count = coop_compact(lds, sel, row);
+    QSTAMP(1);
     const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
     const int A = a.net.n_actions;
     for (int t0 = 0; t0 < count; t0 += 32) {
         const int rowc = t0 + c < count ? list[t0 + c] : -1;
-        __syncthreads();                                                      // previous tile's readers are done
-        coop_load_rows(lds + CoopLds::Xs, a.states, a.row_stride, a.net.state_dim, rowc, wv, c, h);
-        const f32x16 qv = coop_forward<false, VEC>(a.net, lds, wv, c, h, 0, 0, 0, 0, 1.0f);
+        lds_barrier();                                                        // previous tile's readers are done
+        coop_load_rows(lds + CoopLds::Xs, a.states, a.row_stride, K1, rowc, wv, c, h);
+        const f32x16 qv = coop_forward_eval<NK1>(w1r, a.net, lds, Bs, wv, c, h);
         if (wv == 0) {
             const bool live = rowc >= 0;
             if (a.q_out && live) {
@@ -521,7 +658,9 @@ __global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
                 a.actions[rowc] = explore ? (int64_t)rand_below(rnd.y, A) : (int64_t)arg;        // :248-250
             }
         }
+        QSTAMP(7);
     }
+    QSTAMP(8);
 }
 
 // ================================================================ training step (Player.py:255-294)
@@ -544,18 +683,57 @@ __global__ __launch_bounds__(256) void qnet_act4_kernel(const QNetArgs a) {
 // (qnet_adamw_kernel) is mean / clip_grad_norm_ / AdamW / target sync, elementwise over the parameters.
 struct TrainArgs {
     PulseQNet net, tgt;
-    float* partials;                          // [gridDim.x][kSlicePitch]: gradient blocks, biases, then {rows, sum td^2, sum reward, -}
+    float* partials;                          // [gridDim.x][kSlicePitch]: gradient blocks, biases, then {rows, sum td^2, -, used}
     float* scal;                              // scal[0] = squared gradient norm of the reduce launch: cleared here for it
     int n_params;
     const float* states; long long stride;
     const int64_t* actions; const float* rewards;
     const float* next_states; long long next_stride;
-    const uint8_t* dones; const uint8_t* row_mask;
-    uint8_t* terminated;                      // nullptr or in/out: terminated[r] |= dones[r] for every row (trainGPU.py:86)
+    const uint8_t* dones;
+    const int32_t* sel_rows; const int32_t* sel_counts;   // the select launch's lists: sel_rows[256 w + i], i < sel_counts[w]
     int n_rows;
     uint64_t seed, step, table_id0;
     float gamma, drop_p;
 };
+
+// Launch 0 (qnet_select_kernel), one workgroup per window of 256 candidate rows: everything train_step and the trainer do
+// per CANDIDATE row -- the reference's filters (row_mask, seat status ACTIVE / ALLIN, Player.py:258-261) compacted into
+// the window's list of selected rows, `terminated |= dones` (trainGPU.py:86), the window's reward sum over the row_mask
+// rows (trainGPU.py:96).  The training launch then deals the selected rows of the WHOLE batch evenly to its workgroups:
+// with per-window tiles a window holding 33 selected rows (7 % of them at a tenth selected) cost its workgroup two tiles
+// and the launch twice the time of the other 93 %.
+struct SelectArgs {
+    const float* states; long long stride; const float* rewards; const uint8_t* dones; const uint8_t* row_mask;
+    uint8_t* terminated; int n_rows;
+    int32_t* sel_rows; int32_t* sel_counts; float* win_reward;
+};
+
+__global__ __launch_bounds__(256) void qnet_select_kernel(const SelectArgs a) {
+    __shared__ int wcount[4];
+    __shared__ float wrew[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    bool sel = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
+    float rew = sel ? a.rewards[row] : 0.0f;                     // episode reward: rows of row_mask, before the status filter
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rew += __shfl_xor(rew, off);
+    if (a.terminated && row < a.n_rows && a.dones[row]) a.terminated[row] = 1;
+    if (sel) {                                                   // seat status ACTIVE or ALLIN, Player.py:261
+        const float status = a.states[(size_t)row * a.stride + 12];
+        sel = status == 0.0f || status == 2.0f;
+    }
+    const unsigned long long m = __ballot(sel);
+    if (lane == 0) { wcount[wv] = __popcll(m); wrew[wv] = rew; }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base += i < wv ? wcount[i] : 0;
+    if (sel) a.sel_rows[(size_t)blockIdx.x * 256 + base + __popcll(m & ((1ull << lane) - 1ull))] = row;
+    if (threadIdx.x == 0) {
+        a.sel_counts[blockIdx.x] = (wcount[0] + wcount[1]) + (wcount[2] + wcount[3]);
+        a.win_reward[blockIdx.x] = (wrew[0] + wrew[1]) + (wrew[2] + wrew[3]);
+    }
+}
 
 // A workgroup's gradient slice is private scratch, so its layout is the accumulators' own: 35 blocks of 32x32 (layer 1:
 // 4x2, layer 2: 4x4, layer 3: 2x4, layer 4: 1x2, layer 5: 1x1 -- padded rows / columns included), each stored as
@@ -634,13 +812,12 @@ __device__ __forceinline__ void back_block(const float* __restrict__ w, int n_ou
     }
 }
 
-template <bool VEC>
+template <bool VEC, int NK1>
 __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     extern __shared__ float lds[];
     const PulseQNet& n = a.net;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane & 31, h0 = lane >> 5;
     const int K1 = n.state_dim, A = n.n_actions;
-    const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
     float* A4 = lds + CoopLds::A4;
     float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
@@ -651,7 +828,6 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     // this wavefront's rows of db, live across every tile of the launch (its blocks of dW accumulate in the slice)
     float b5 = 0.0f, b4 = 0.0f, b3 = 0.0f, b2 = 0.0f, b1 = 0.0f;
     float rows_sum = 0.0f, sq_sum = 0.0f;                        // wavefront 0, lane-replicated after the reductions
-    float reward_sum = 0.0f;                                     // this wavefront's candidate rows
     bool used = false;
     float* part = a.partials + (size_t)blockIdx.x * kSlicePitch;
 
@@ -659,22 +835,33 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     // launch: this kernel sits between the two on the stream, so its first thread clears it
     if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[0] = 0.0f;
     QSTAMP(0);
-    const int n_windows = (a.n_rows + 255) / 256;
-    for (int win = blockIdx.x; win < n_windows; win += gridDim.x) {
-        const int row = win * 256 + threadIdx.x;
-        bool sel = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
-        float rew = sel ? a.rewards[row] : 0.0f;                 // episode reward: rows of row_mask, before the status filter (trainGPU.py:96)
+    // The selected rows of the whole batch, in window order, are positions [0, T); every workgroup computes the same
+    // exclusive sums of the windows' counts (thread t: windows [t per, (t + 1) per)) and takes the tiles ti = blockIdx.x,
+    // + gridDim.x, ... of an even split of [0, T) into n_tiles <= 32-row pieces.
+    const int n_windows = (a.n_rows + 255) / 256, per = (n_windows + 255) / 256;
+    int* chunk = reinterpret_cast<int*>(lds + CoopLds::List);    // [256] first position of thread t's windows, [256] = T
+    int T;
+    {
+        int mine = 0;
+        for (int j = 0; j < per; ++j) { const int w = threadIdx.x * per + j; mine += w < n_windows ? a.sel_counts[w] : 0; }
+        int incl = mine;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) rew += __shfl_xor(rew, off);
-        reward_sum += rew;
-        if (a.terminated && row < a.n_rows && a.dones[row]) a.terminated[row] = 1;
-        if (sel) {                                               // seat status ACTIVE or ALLIN, Player.py:261
-            const float status = a.states[(size_t)row * a.stride + 12];
-            sel = status == 0.0f || status == 2.0f;
-        }
-        __syncthreads();                                         // previous window's tiles are done with List
-        const int count = coop_compact(lds, sel, row);
-        for (int t0 = 0; t0 < count; t0 += 32) {
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); incl += lane >= off ? o : 0; }
+        int* wtot = chunk + 257;
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base += i < wv ? wtot[i] : 0;
+        chunk[threadIdx.x] = base + incl - mine;
+        T = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+        __syncthreads();
+    }
+    const int G = (int)gridDim.x;
+    const int r_tile = min(32, max(8, (T + G - 1) / G));
+    const int n_tiles = (T + r_tile - 1) / r_tile;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
+        {
             const bool first = !used;
             used = true;
             // the addresses below depend only on the wavefront and the lane: without this opaque zero the compiler
@@ -684,18 +871,33 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             float* part_t = part + opaque;
             int c = c0, h = h0;
             asm volatile("" : "+v"(c), "+v"(h));
-            const int rowc = t0 + c < count ? list[t0 + c] : -1;
+            // column c = position lo + c of the batch's selected rows: its window by bisection of the threads' first
+            // positions (the last t with chunk[t] <= p has a non-empty range holding p), then along that thread's windows
+            const int lo = (int)((long long)ti * T / n_tiles), hi = (int)((long long)(ti + 1) * T / n_tiles);
+            int rowc = -1;
+            if (lo + c < hi) {
+                const int p = lo + c;
+                int t = 0;
+#pragma unroll
+                for (int s = 128; s >= 1; s >>= 1) t += (chunk[t + s] <= p) ? s : 0;
+                int w = t * per, acc = chunk[t], cnt = a.sel_counts[w];
+                while (p >= acc + cnt) { acc += cnt; ++w; cnt = a.sel_counts[w]; }
+                rowc = a.sel_rows[(size_t)w * 256 + (p - acc)];
+            }
             const bool live = rowc >= 0;
             const int rw = max(rowc, 0);
             const uint64_t gid = a.table_id0 + (uint64_t)rw;
             // both forwards together: target r + gamma * max_a' Q_target(s', a') * (1 - done) (:275-277), network in train mode
             __syncthreads();
             QSTAMP(1);
+            float w1t[NK1][4], w1c[NK1][4];
+            load_layer<VEC, NK1>(w1t, a.tgt, 0, 32 * wv + c, h, 0, (K1 + 7) & ~7);
+            load_layer<VEC, NK1>(w1c, n, 0, 32 * wv + c, h, 0, (K1 + 7) & ~7);
             coop_load_rows(lds + CoopLds::Db, a.next_states, a.next_stride, K1, rowc, wv, c, h);
             coop_load_rows(lds + CoopLds::Xs, a.states, a.stride, K1, rowc, wv, c, h);
             {
                 f32x16 qn, qv;
-                coop_forward_pair<VEC>(a.tgt, n, lds, wv, c, h, a.seed, gid, a.step, thr, scale, qn, qv);
+                coop_forward_pair<VEC, NK1>(w1t, w1c, a.tgt, n, lds, wv, c, h, a.seed, gid, a.step, thr, scale, qn, qv);
                 QSTAMP(2);
                 if (wv == 0) {                                                // delta_5 and the loss terms (:270-279)
                     float best = -INFINITY;
@@ -752,7 +954,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     }
 
     QSTAMP(8);
-    if (!used) {                                                  // no valid row in any of this workgroup's windows: a zero slice
+    if (!used) {                                                  // no tile for this workgroup: a zero slice
         for (int i = threadIdx.x; i < kSliceStats; i += 256) part[i] = 0.0f;
     } else if (K1 <= 32) {                                        // the second column tile of layer 1 was never touched
         for (int i = threadIdx.x; i < 4 * 1024; i += 256) part[(size_t)(kSliceBlk1 + 2 * (i >> 10) + 1) * 1024 + (i & 1023)] = 0.0f;
@@ -764,14 +966,9 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
         part[kSliceBias + 128 + 32 * wv + c0] = b2;
         part[kSliceBias + 32 * wv + c0] = b1;
     }
-    float* wave_reward = lds + CoopLds::List + 260;               // 4 spare words behind the compaction counters
-    __syncthreads();
-    if (lane == 0) wave_reward[wv] = reward_sum;
-    __syncthreads();
     if (wv == 0 && lane == 0) {
         float* ps = part + kSliceStats;
-        ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = (wave_reward[0] + wave_reward[1]) + (wave_reward[2] + wave_reward[3]);
-        ps[3] = used ? 1.0f : 0.0f;
+        ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = 0.0f; ps[3] = used ? 1.0f : 0.0f;
     }
     QSTAMP(9);
 }
@@ -782,6 +979,7 @@ struct ReduceArgs {
     const float* partials; int n_blocks, n_params, state_dim, n_actions;
     float* grad; float* scal;                 // scal: [0] sum g^2 (zeroed here by the previous step's AdamW), [1] rows, [2] sum td^2
     long long* step; double* reward_sum;      // reward_sum: nullptr or += sum of rewards over row_mask rows
+    const float* win_reward; int n_windows;   // the select launch's per-window reward sums
 };
 
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a) {
@@ -818,7 +1016,8 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
             const int col = threadIdx.x >> 2, comp = threadIdx.x & 3;
 #pragma unroll
             for (int q = 0; q < 8; ++q) g += reinterpret_cast<const float*>(&part8[q][col])[comp];
-            a.grad[slice_param(j, a.state_dim, a.n_actions)] = g;
+            const int i = slice_param(j, a.state_dim, a.n_actions);  // -1: a padding element of the slice layout
+            if (i >= 0 && i < a.n_params) a.grad[i] = g; else g = 0.0f;
         }
     }
     float ss = g * g;
@@ -831,8 +1030,9 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
         float rows = 0.0f, sq = 0.0f; double rew = 0.0;
         for (int b = threadIdx.x; b < a.n_blocks; b += 64) {
             const float* ps = a.partials + b * pitch + kSliceStats;
-            rows += ps[0]; sq += ps[1]; rew += (double)ps[2];
+            rows += ps[0]; sq += ps[1];
         }
+        if (a.reward_sum) for (int w = threadIdx.x; w < a.n_windows; w += 64) rew += (double)a.win_reward[w];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { rows += __shfl_xor(rows, off); sq += __shfl_xor(sq, off); rew += __shfl_xor(rew, off); }
         if (threadIdx.x == 0) {
@@ -893,16 +1093,21 @@ int launch(const QNetArgs& a, void* stream) {
     if (select && n.state_dim > 64) {        // wider inputs than the cooperative tile's LDS image: one wavefront per tile
         if (vec) hipLaunchKernelGGL((qnet_kernel<true, true>), dim3(grid), dim3(64), 0, st, a); else hipLaunchKernelGGL((qnet_kernel<true, false>), dim3(grid), dim3(64), 0, st, a);
     } else if (select) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_act4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLdsBytes);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_act4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLdsBytes);
+        const int slot = vec ? (n.state_dim <= 40 ? 0 : 1) : 2;
+        const void* fns[3] = {reinterpret_cast<const void*>(&qnet_act4_kernel<true, kActWin, 5>),
+                              reinterpret_cast<const void*>(&qnet_act4_kernel<true, kActWin, 8>),
+                              reinterpret_cast<const void*>(&qnet_act4_kernel<false, kActWin, 8>)};
+        const void* fn = fns[slot];
+        static const void* attr_set[3] = {nullptr, nullptr, nullptr};
+        if (attr_set[slot] != fn) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLdsBytes);
             if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_act: LDS size attribute");
-            attr_set = true;
+            attr_set[slot] = fn;
         }
-        const unsigned g4 = (unsigned)((a.n_rows + 255) / 256);
-        if (vec) hipLaunchKernelGGL((qnet_act4_kernel<true>), dim3(g4), dim3(256), kActLdsBytes, st, a);
-        else hipLaunchKernelGGL((qnet_act4_kernel<false>), dim3(g4), dim3(256), kActLdsBytes, st, a);
+        const unsigned g4 = (unsigned)((a.n_rows + kActWin - 1) / kActWin);
+        void* params[1] = {const_cast<QNetArgs*>(&a)};
+        const hipError_t le = hipLaunchKernel(fn, dim3(g4), dim3(256), params, kActLdsBytes, st);
+        if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_act launch");
     }
     else { if (vec) hipLaunchKernelGGL((qnet_kernel<false, true>), dim3(grid), dim3(64), 0, st, a); else hipLaunchKernelGGL((qnet_kernel<false, false>), dim3(grid), dim3(64), 0, st, a); }
     const hipError_t e = hipGetLastError();
@@ -986,25 +1191,38 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
         TrainArgs a{};
         a.net = t->net; a.tgt = t->target; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
         a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
-        a.row_mask = row_mask; a.terminated = terminated; a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
+        a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
         a.gamma = t->gamma; a.drop_p = t->dropout_p;
+        const int n_windows = (n_rows + 255) / 256;
+        if (!t->select_scratch || t->select_words < (int64_t)n_windows * 258)
+            return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: select_scratch must hold 258 words per 256 rows");
+        SelectArgs sa{};
+        sa.states = states; sa.stride = row_stride; sa.rewards = rewards; sa.dones = dones; sa.row_mask = row_mask; sa.terminated = terminated;
+        sa.n_rows = n_rows; sa.sel_rows = t->select_scratch; sa.sel_counts = t->select_scratch + (size_t)n_windows * 256;
+        sa.win_reward = reinterpret_cast<float*>(t->select_scratch + (size_t)n_windows * 257);
+        a.sel_rows = sa.sel_rows; a.sel_counts = sa.sel_counts;
+        hipLaunchKernelGGL(qnet_select_kernel, dim3((unsigned)n_windows), dim3(256), 0, st, sa);
         const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
+        // instances: layer-1 steps 5 (16-byte rows of <= 40 inputs) or 8
+        const void* fns[3] = {reinterpret_cast<const void*>(&qnet_train_kernel<false, 8>), reinterpret_cast<const void*>(&qnet_train_kernel<true, 8>),
+                              reinterpret_cast<const void*>(&qnet_train_kernel<true, 5>)};
+        const int slot = vec ? (n.state_dim <= 40 ? 2 : 1) : 0;
+        static const void* attr_set[3] = {nullptr, nullptr, nullptr};
+        if (attr_set[slot] != fns[slot]) {
+            const hipError_t e = hipFuncSetAttribute(fns[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
             if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
-            attr_set = true;
-    }
-    // persistent workgroups (4 wavefronts, 149 KB of LDS: one per CU) striding over the 256-row windows
-    const int grid = std::min((n_rows + 255) / 256, (int)t->max_blocks);
-    if (vec) hipLaunchKernelGGL((qnet_train_kernel<true>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
-    else hipLaunchKernelGGL((qnet_train_kernel<false>), dim3((unsigned)grid), dim3(256), kTrainLdsBytes, st, a);
+            attr_set[slot] = fns[slot];
+        }
+        // persistent workgroups (4 wavefronts, 157 KB of LDS: one per CU); a tile holds at least 8 selected rows
+        const int grid = std::min((n_rows + 7) / 8, (int)t->max_blocks);
+        void* params[1] = {&a};
+        const hipError_t le = hipLaunchKernel(fns[slot], dim3((unsigned)grid), dim3(256), params, kTrainLdsBytes, st);
+        if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_train_step launch");
     ReduceArgs r{};
     r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
     r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
-    r.reward_sum = reward_sum;
+    r.reward_sum = reward_sum; r.win_reward = sa.win_reward; r.n_windows = n_windows;
     hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3((unsigned)((kSliceStats + 127) / 128)), dim3(256), 0, st, r);
     }
     if (apply && (n_rows > 0 || !grads)) {

@@ -172,7 +172,7 @@ class PokerQNetwork(nn.Module):
             flats.append(flat)
         self._flat, self._flat_target = flats
 
-    def _native_state(self):
+    def _native_state(self, n_rows=0):
         nat = self._native
         if nat is None:
             if getattr(self, "_flat", None) is None:
@@ -189,6 +189,10 @@ class PokerQNetwork(nn.Module):
                 "partials": torch.empty(TRAIN_BLOCKS * _native.lib().pulse_qnet_slice_floats(), dtype=torch.float32,
                                         device=dev),                                            # 37 MB at 256 workgroups
             }
+        words = 258 * ((max(int(n_rows), 1 << 16) + 255) // 256)              # the row-selection launch's lists (pulse_env.h)
+        if nat.get("select") is None or nat["select"].numel() < words:
+            nat["select"] = torch.empty(words, dtype=torch.int32, device=self._flat.device)
+            self._struct_cache.pop("train", None)
         t = self._struct_cache.get("train")
         if t is not None and t.params == self._flat.data_ptr():
             t.lr, t.weight_decay, t.gamma, t.update_freq = self.lr, self.wd, float(self.gamma), int(self.update_freq)
@@ -200,6 +204,7 @@ class PokerQNetwork(nn.Module):
         t.grad, t.exp_avg, t.exp_avg_sq = nat["grad"].data_ptr(), nat["m"].data_ptr(), nat["v"].data_ptr()
         t.step, t.stats, t.report = nat["step"].data_ptr(), nat["stats"].data_ptr(), nat["report"].data_ptr()
         t.partials, t.max_blocks = nat["partials"].data_ptr(), TRAIN_BLOCKS
+        t.select_scratch, t.select_words = nat["select"].data_ptr(), nat["select"].numel()
         t.lr, t.weight_decay, t.beta1, t.beta2, t.eps = self.lr, self.wd, 0.9, 0.999, 1e-8       # torch.optim.AdamW defaults (:296)
         t.max_grad_norm, t.gamma = 1.0, float(self.gamma)                                      # clip_grad_norm_ (:280)
         t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
@@ -217,7 +222,7 @@ class PokerQNetwork(nn.Module):
         Moments live in this path's own buffers (not in self.optimizer, which serves the torch train_step)."""
         states, next_states = self._rows(states), self._rows(next_states)
         n = states.shape[0]
-        t = self._native_state()
+        t = self._native_state(n)
         if n == 0:                            # nothing to learn from: the reference returns before the optimizer (:262)
             return self._native["report"]
 

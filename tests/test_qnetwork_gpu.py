@@ -313,6 +313,44 @@ def test_native_training_reduces_td_error_on_a_fixed_batch(g):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
+@pytest.mark.parametrize("net", ["s40", "s64"])
+def test_native_train_step_writes_only_inside_its_buffers(g, net):
+    """Guard words either side of the gradient, the moments and the slice scratch stay untouched by a training step (the
+    slice layout has padding elements that map to no parameter: they must be dropped, not written at index -1)."""
+    if net == "s64":
+        from pulselib_amd.environments.Poker import PokerQNetwork
+        torch.manual_seed(64)
+        q = PokerQNetwork(None, torch.device(DEV), gamma=.97, update_freq=3, state_dim=64, action_dim=13, learning_rate=1e-3,
+                          weight_decay=0.01, seed=8)
+        rng = np.random.default_rng(5)
+        n = 3000
+        b = dict(states=rng.standard_normal((n, 64)).astype(np.float32), actions=rng.integers(0, 13, n),
+                 rewards=rng.standard_normal(n).astype(np.float32), next_states=rng.standard_normal((n, 64)).astype(np.float32),
+                 dones=rng.random(n) < 0.1, row_mask=rng.random(n) < 0.8)
+        b["states"][:, 12] = rng.integers(0, 4, n)       # seat status column: some rows are not trainable
+    else:
+        q = _qnet(g, "s40", seed=4)
+        b = _batch(3000, 13)
+    dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
+    q._native_state()
+    nat, guard, fill = q._native, 256, 12345.0
+    held = {}
+    for name in ("grad", "m", "v", "partials"):
+        n_el = nat[name].numel()
+        big = torch.full((n_el + 2 * guard,), fill, dtype=torch.float32, device=DEV)
+        big[guard:guard + n_el] = 0.0
+        held[name] = big
+        nat[name] = big[guard:guard + n_el]
+    q._struct_cache.pop("train", None)                   # the cached struct holds the old pointers
+    for _ in range(3):
+        q.train_step_native(dev["states"], dev["actions"], dev["rewards"], dev["next_states"], dev["dones"], dev["row_mask"])
+    torch.cuda.synchronize()
+    for name, big in held.items():
+        n_el = nat[name].numel()
+        assert bool((big[:guard] == fill).all()) and bool((big[guard + n_el:] == fill).all()), name
+    assert float(nat["grad"].abs().sum()) > 0.0
+
+
 def test_native_train_step_folds_trainer_bookkeeping(g):
     """terminated |= dones and reward_sum += rewards[row_mask] ride along with the training launches (trainGPU.py:86,96)."""
     q = _qnet(g, "s40", seed=2)

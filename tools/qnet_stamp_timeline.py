@@ -12,7 +12,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from pulselib_amd import _native  # noqa: E402
 
-_native._SO = ROOT / "pulselib_amd" / "libpulse_hip_stamps.so"
+import os  # noqa: E402
+_native._SO = Path(os.environ.get("PULSE_STAMPS_LIB", ROOT / "pulselib_amd" / "libpulse_hip_stamps.so"))
 from pulselib_amd.environments.Poker import PokerQNetwork  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
