@@ -410,7 +410,7 @@ typedef struct PulseQNetTrain {
     float lr, weight_decay, beta1, beta2, eps, max_grad_norm, gamma, dropout_p;
     int32_t update_freq, max_blocks;
     int32_t* select_scratch;        /* device int32[select_words]: the row-selection launch's lists */
-    int64_t select_words;           /* >= 258 * ceil(n_rows / 256) for the largest n_rows passed */
+    int64_t select_words;           /* >= 258 * ceil(n_rows / 256) + 512 for the largest n_rows passed */
 } PulseQNetTrain;
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions);
 int pulse_qnet_slice_floats(void);

@@ -691,6 +691,7 @@ struct TrainArgs {
     const float* next_states; long long next_stride;
     const uint8_t* dones;
     const int32_t* sel_rows; const int32_t* sel_counts;   // the select launch's lists: sel_rows[256 w + i], i < sel_counts[w]
+    unsigned* meet;
     int n_rows;
     uint64_t seed, step, table_id0;
     float gamma, drop_p;
@@ -833,6 +834,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
 
     // scal[0] is read by every workgroup of the previous step's AdamW launch and accumulated by this step's reduce
     // launch: this kernel sits between the two on the stream, so its first thread clears it
+    if (blockIdx.x == 0 && threadIdx.x < 8) a.meet[threadIdx.x] = 0u;          // the fused reduce launch's arrival counters
     if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[0] = 0.0f;
     QSTAMP(0);
     // The selected rows of the whole batch, in window order, are positions [0, T); every workgroup computes the same
@@ -980,9 +982,38 @@ struct ReduceArgs {
     float* grad; float* scal;                 // scal: [0] sum g^2 (zeroed here by the previous step's AdamW), [1] rows, [2] sum td^2
     long long* step; double* reward_sum;      // reward_sum: nullptr or += sum of rewards over row_mask rows
     const float* win_reward; int n_windows;   // the select launch's per-window reward sums
+    unsigned* meet;                           // fused form: [0..8) arrival counters (zero at launch), [8 + b] workgroup b's sum of g^2
 };
 
-__global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a) {
+struct AdamArgs {
+    float* params; float* target; const float* grad; float* m; float* v; const long long* step; float* scal; float* report;
+    int n_params; float lr, wd, beta1, beta2, eps, max_norm; int update_freq;
+};
+
+// the AdamW update of parameter i (torch semantics: decoupled decay, bias-corrected moments) from the gradient SUM g over
+// `count` rows, `ss` = squared norm of the summed gradient, t = optimizer step of this update
+__device__ __forceinline__ void adamw_one(const AdamArgs& a, int i, float g_sum, float count, float ss, long long t) {
+    const float inv = 1.0f / count;
+    const float norm = sqrtf(ss) * inv;                                           // norm of the mean gradient
+    const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f) * inv;            // torch.nn.utils.clip_grad_norm_
+    const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
+    const float step_size = a.lr / bc1, bc2_sqrt = sqrtf(bc2);
+    const float g = g_sum * coef;
+    float p = a.params[i] * (1.0f - a.lr * a.wd);
+    const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+    p -= step_size * (m / (sqrtf(v) / bc2_sqrt + a.eps));
+    a.m[i] = m; a.v[i] = v; a.params[i] = p;
+    if (a.update_freq > 0 && (t % a.update_freq) == 0) a.target[i] = p;
+}
+
+// FUSED: the AdamW step rides in the same launch.  Every workgroup needs the squared norm of the WHOLE gradient for the
+// clipping factor, so the workgroups (282 of 256 threads: all resident at once) meet at a counter after publishing their part
+// of it; each then updates the parameters whose gradient sums it holds in registers.  Saves the third launch's dispatch
+// and its 4.7 us for a wait of about one.  Everything a workgroup reads that another wrote in this launch goes through
+// device-scope atomics (the norm, the counter): the per-XCD L2s are not coherent for plain loads.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a, const AdamArgs w) {
     __shared__ float red[4];
     __shared__ float4 part8[8][32];
     // 128 slice elements per workgroup as 32 float4 columns; the workgroups' slices are split between the eight 32-lane groups
@@ -1010,6 +1041,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     part8[grp][lane] = acc;
     __syncthreads();
     float g = 0.0f;                                              // threads 0..127: element j0' = blockIdx.x * 128 + threadIdx.x
+    int pi = -1;
     if (threadIdx.x < 128) {
         const int j = blockIdx.x * 128 + threadIdx.x;
         if (j < kSliceStats) {
@@ -1017,7 +1049,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
 #pragma unroll
             for (int q = 0; q < 8; ++q) g += reinterpret_cast<const float*>(&part8[q][col])[comp];
             const int i = slice_param(j, a.state_dim, a.n_actions);  // -1: a padding element of the slice layout
-            if (i >= 0 && i < a.n_params) a.grad[i] = g; else g = 0.0f;
+            if (i >= 0 && i < a.n_params) { a.grad[i] = g; pi = i; } else g = 0.0f;
         }
     }
     float ss = g * g;
@@ -1025,20 +1057,61 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(a.scal + 0, (red[0] + red[1]) + (red[2] + red[3]));
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        float rows = 0.0f, sq = 0.0f; double rew = 0.0;
+    __shared__ float bc[2];
+    __shared__ long long step_old;
+    if (threadIdx.x == 0) {
+        const float part = (red[0] + red[1]) + (red[2] + red[3]);
+        if (FUSED) {
+            // this workgroup's part of the norm goes to its own word, then it is counted on one of 8 counters (282 arrivals
+            // on one address serialise at ~60 ns each: 6 us of the first version of this meeting)
+            step_old = *a.step;                                    // (workgroup 0 advances it after the meeting)
+            __hip_atomic_store(reinterpret_cast<float*>(a.meet + 8 + blockIdx.x), part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the store has left before the arrival is sent after it
+            asm volatile("" :: "v"((int)step_old));
+            __hip_atomic_fetch_add(a.meet + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsafeAtomicAdd(a.scal + 0, part);
+        }
+    }
+    float rows = 0.0f, sq = 0.0f; double rew = 0.0;
+    if ((FUSED || blockIdx.x == 0) && threadIdx.x < 64) {        // fused: every workgroup totals the row count itself
         for (int b = threadIdx.x; b < a.n_blocks; b += 64) {
             const float* ps = a.partials + b * pitch + kSliceStats;
             rows += ps[0]; sq += ps[1];
         }
-        if (a.reward_sum) for (int w = threadIdx.x; w < a.n_windows; w += 64) rew += (double)a.win_reward[w];
+        if (blockIdx.x == 0 && a.reward_sum) for (int wdw = threadIdx.x; wdw < a.n_windows; wdw += 64) rew += (double)a.win_reward[wdw];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { rows += __shfl_xor(rows, off); sq += __shfl_xor(sq, off); rew += __shfl_xor(rew, off); }
-        if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
             a.scal[1] = rows; a.scal[2] = sq;
-            if (rows > 0.0f && a.step) *a.step += 1;
+            if (!FUSED && rows > 0.0f && a.step) *a.step += 1;
             if (a.reward_sum) *a.reward_sum += rew;
+        }
+    }
+    if (FUSED) {
+        if (threadIdx.x < 64) {                                   // wavefront 0: lanes 0..7 watch one counter each
+            const unsigned want = (gridDim.x + 7 - (threadIdx.x & 7)) / 8;      // workgroups b with b % 8 == lane
+            for (;;) {
+                const unsigned got = threadIdx.x < 8 ? __hip_atomic_load(a.meet + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+                if (__ballot(got < want) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            float tot = 0.0f;                                      // the same order in every workgroup: the update does not depend on timing
+            for (unsigned b = threadIdx.x; b < gridDim.x; b += 64)
+                tot += __hip_atomic_load(reinterpret_cast<float*>(a.meet + 8 + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+            if (threadIdx.x == 0) { bc[0] = tot; bc[1] = rows; }
+        }
+        __syncthreads();
+        const float total_ss = bc[0], count = bc[1];
+        const long long t = step_old + 1;
+        if (count > 0.0f && pi >= 0) adamw_one(w, pi, g, count, total_ss, t);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (count > 0.0f) *a.step = t;
+            a.scal[0] = total_ss;
+            const float inv = count > 0.0f ? 1.0f / count : 0.0f;
+            w.report[0] = count; w.report[1] = sq * inv; w.report[2] = sqrtf(total_ss) * inv;
         }
     }
 }
@@ -1047,30 +1120,13 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
 // (Player.py:280-292): gradient /= #valid rows (MSELoss mean), clip_grad_norm_(max_norm), AdamW (torch semantics:
 // decoupled decay, bias-corrected moments), target sync every update_freq optimizer steps (:289-290).  No valid row:
 // nothing moves (the reference returns before the optimizer, :262).
-struct AdamArgs {
-    float* params; float* target; const float* grad; float* m; float* v; const long long* step; float* scal; float* report;
-    int n_params; float lr, wd, beta1, beta2, eps, max_norm; int update_freq;
-};
 
 __global__ __launch_bounds__(256) void qnet_adamw_kernel(const AdamArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float count = a.scal[1], sq = a.scal[2], ss = a.scal[0];
     const float inv = count > 0.0f ? 1.0f / count : 0.0f;
-    const float norm = sqrtf(ss) * inv;                                           // norm of the mean gradient
-    if (count > 0.0f && i < a.n_params) {
-        const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f) * inv;        // torch.nn.utils.clip_grad_norm_
-        const long long t = *a.step;                                              // already advanced by the reduce launch
-        const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
-        const float step_size = a.lr / bc1, bc2_sqrt = sqrtf(bc2);
-        const float g = a.grad[i] * coef;
-        float p = a.params[i] * (1.0f - a.lr * a.wd);
-        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
-        p -= step_size * (m / (sqrtf(v) / bc2_sqrt + a.eps));
-        a.m[i] = m; a.v[i] = v; a.params[i] = p;
-        if (a.update_freq > 0 && (t % a.update_freq) == 0) a.target[i] = p;
-    }
-    if (i == 0) { a.report[0] = count; a.report[1] = count > 0.0f ? sq * inv : 0.0f; a.report[2] = norm; }
+    if (count > 0.0f && i < a.n_params) adamw_one(a, i, a.grad[i], count, ss, *a.step);   // (step already advanced by the reduce launch)
+    if (i == 0) { a.report[0] = count; a.report[1] = count > 0.0f ? sq * inv : 0.0f; a.report[2] = sqrtf(ss) * inv; }
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -1154,6 +1210,14 @@ int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions) {
 }
 
 namespace {
+AdamArgs adam_args(const PulseQNetTrain* t, int np) {
+    AdamArgs b{};
+    b.params = t->params; b.target = t->target_params; b.grad = t->grad; b.m = t->exp_avg; b.v = t->exp_avg_sq; b.step = (const long long*)t->step;
+    b.scal = t->stats; b.report = t->report; b.n_params = np; b.lr = t->lr; b.wd = t->weight_decay; b.beta1 = t->beta1; b.beta2 = t->beta2;
+    b.eps = t->eps; b.max_norm = t->max_grad_norm; b.update_freq = t->update_freq;
+    return b;
+}
+
 int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
                    const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
                    const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
@@ -1187,6 +1251,7 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     if (n_rows < 0) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: n_rows < 0");
     hipStream_t st = (hipStream_t)stream;
     const unsigned eg = (unsigned)((np + 255) / 256);
+    bool fused = false;
     if (grads && n_rows > 0) {
         TrainArgs a{};
         a.net = t->net; a.tgt = t->target; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
@@ -1194,13 +1259,14 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
         a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
         a.gamma = t->gamma; a.drop_p = t->dropout_p;
         const int n_windows = (n_rows + 255) / 256;
-        if (!t->select_scratch || t->select_words < (int64_t)n_windows * 258)
-            return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: select_scratch must hold 258 words per 256 rows");
+        if (!t->select_scratch || t->select_words < (int64_t)n_windows * 258 + 512)
+            return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: select_scratch must hold 258 words per 256 rows + 512");
         SelectArgs sa{};
         sa.states = states; sa.stride = row_stride; sa.rewards = rewards; sa.dones = dones; sa.row_mask = row_mask; sa.terminated = terminated;
         sa.n_rows = n_rows; sa.sel_rows = t->select_scratch; sa.sel_counts = t->select_scratch + (size_t)n_windows * 256;
         sa.win_reward = reinterpret_cast<float*>(t->select_scratch + (size_t)n_windows * 257);
         a.sel_rows = sa.sel_rows; a.sel_counts = sa.sel_counts;
+        a.meet = reinterpret_cast<unsigned*>(t->select_scratch + (size_t)n_windows * 258);
         hipLaunchKernelGGL(qnet_select_kernel, dim3((unsigned)n_windows), dim3(256), 0, st, sa);
         const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
         // instances: layer-1 steps 5 (16-byte rows of <= 40 inputs) or 8
@@ -1222,14 +1288,15 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
     r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
-    r.reward_sum = reward_sum; r.win_reward = sa.win_reward; r.n_windows = n_windows;
-    hipLaunchKernelGGL(qnet_grad_reduce_kernel, dim3((unsigned)((kSliceStats + 127) / 128)), dim3(256), 0, st, r);
+    r.reward_sum = reward_sum; r.win_reward = sa.win_reward; r.n_windows = n_windows; r.meet = a.meet;
+    fused = apply;                                             // one GPU: AdamW rides in the reduce launch
+    AdamArgs b = adam_args(t, np);
+    const unsigned rg = (unsigned)((kSliceStats + 127) / 128);
+    if (fused) hipLaunchKernelGGL(qnet_grad_reduce_kernel<true>, dim3(rg), dim3(256), 0, st, r, b);
+    else hipLaunchKernelGGL(qnet_grad_reduce_kernel<false>, dim3(rg), dim3(256), 0, st, r, b);
     }
-    if (apply && (n_rows > 0 || !grads)) {
-        AdamArgs b{};
-        b.params = t->params; b.target = t->target_params; b.grad = t->grad; b.m = t->exp_avg; b.v = t->exp_avg_sq; b.step = (const long long*)t->step;
-        b.scal = t->stats; b.report = t->report; b.n_params = np; b.lr = t->lr; b.wd = t->weight_decay; b.beta1 = t->beta1; b.beta2 = t->beta2;
-        b.eps = t->eps; b.max_norm = t->max_grad_norm; b.update_freq = t->update_freq;
+    if (apply && !fused && (n_rows > 0 || !grads)) {
+        const AdamArgs b = adam_args(t, np);
         hipLaunchKernelGGL(qnet_adamw_kernel, dim3(eg), dim3(256), 0, st, b);
     }
     const hipError_t e = hipGetLastError();
