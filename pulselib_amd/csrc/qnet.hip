@@ -396,13 +396,19 @@ __device__ __forceinline__ void load_layer(float (&wa)[NK8][4], const PulseQNet&
 }
 
 // hidden layer epilogue: z = acc + bias -> a = gelu(z) * m to As; TRAIN also g = gelu'(z) * m to Gs (m = dropout keep * scale)
+// the 16 biases of this lane's accumulator rows (units unit0 + rho(r) + 4h); `bias` global or LDS
+__device__ __forceinline__ void load_bias16(float (&bz)[16], const float* __restrict__ bias, int unit0, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = bias[unit0 + rho(r) + 4 * h];
+}
+
 template <bool TRAIN>
-__device__ __forceinline__ void coop_epilogue(const f32x16& acc, const float* __restrict__ bias, int unit0, int c, int h, uint32_t keep,
+__device__ __forceinline__ void coop_epilogue(const f32x16& acc, const float (&bz)[16], int unit0, int c, int h, uint32_t keep,
                                               float scale, float* __restrict__ As, float* __restrict__ Gs) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {                             // registers r, r + 1 are units u, u + 1
         const int u = unit0 + rho(r) + 4 * h;
-        const f32x2 z = {acc[r] + bias[u], acc[r + 1] + bias[u + 1]};
+        const f32x2 z = {acc[r] + bz[r], acc[r + 1] + bz[r + 1]};
         const f32x2 m = {((keep >> r) & 1u) ? scale : 0.0f, ((keep >> (r + 1)) & 1u) ? scale : 0.0f};
         f32x2 y, dy;
         if (PULSE_QABL & 2) { y = z; dy = z; } else gelu_pair2(z, y, dy);
@@ -452,7 +458,7 @@ __device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], 
     {   // layer 1: wavefront wv -> units [32wv, +32)
         const f32x16 acc = mfma_w<NK1>(w1r, c, h, Xs, 0);
         load_layer<true, 16>(w2r, n, 1, 32 * wv + c, h, 0, 128);
-        coop_epilogue<false>(acc, Bs, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, nullptr);
+        { float bz[16]; load_bias16(bz, Bs, 32 * wv, h); coop_epilogue<false>(acc, bz, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, nullptr); }
     }
     lds_barrier();
     QSTAMP(3);
@@ -460,7 +466,7 @@ __device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], 
     {   // layer 2
         const f32x16 acc = mfma_w<16>(w2r, c, h, A1, 0);
         load_layer<true, 8>(w3r, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
-        coop_epilogue<false>(acc, Bs + 128, 32 * wv, c, h, 0xFFFFu, 1.0f, A2, nullptr);
+        { float bz[16]; load_bias16(bz, Bs + 128, 32 * wv, h); coop_epilogue<false>(acc, bz, 32 * wv, c, h, 0xFFFFu, 1.0f, A2, nullptr); }
     }
     lds_barrier();
     QSTAMP(4);
@@ -476,7 +482,7 @@ __device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], 
         if (half == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += P[(ot * 16 + r) * 64 + lane];
-            coop_epilogue<false>(acc, Bs + 256, 32 * ot, c, h, 0xFFFFu, 1.0f, A3, nullptr);
+            { float bz[16]; load_bias16(bz, Bs + 256, 32 * ot, h); coop_epilogue<false>(acc, bz, 32 * ot, c, h, 0xFFFFu, 1.0f, A3, nullptr); }
         }
     }
     lds_barrier();
@@ -493,7 +499,7 @@ __device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], 
         if (wv == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += (P[r * 64 + lane] + P[(16 + r) * 64 + lane]) + P[(32 + r) * 64 + lane];
-            coop_epilogue<false>(acc, Bs + 320, 0, c, h, 0xFFFFu, 1.0f, A4, nullptr);
+            { float bz[16]; load_bias16(bz, Bs + 320, 0, h); coop_epilogue<false>(acc, bz, 0, c, h, 0xFFFFu, 1.0f, A4, nullptr); }
         }
     }
     lds_barrier();
@@ -525,27 +531,34 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     const int ot = wv & 1, half = wv >> 1;
     lds_barrier();                                                            // Xs, Xn complete
     float w2t[16][4], w2c[16][4];
-    {   // layer 1
+    {   // layer 1 (each phase: this layer's biases, the MFMAs, the next layer's weights, the epilogues -- a wait for the
+        // biases then never includes the younger weight loads)
+        float bt[16], bo[16];
+        load_bias16(bt, nt.b1, 32 * wv, h); load_bias16(bo, n.b1, 32 * wv, h);
         const f32x16 at = mfma_w<NK1>(w1t, c, h, Xn, 0);
         const f32x16 ac = mfma_w<NK1>(w1c, c, h, Xs, 0);
         load_layer<true, 16>(w2t, nt, 1, 32 * wv + c, h, 0, 128);
         load_layer<true, 16>(w2c, n, 1, 32 * wv + c, h, 0, 128);
-        coop_epilogue<false>(at, nt.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, T1, nullptr);
-        coop_epilogue<true>(ac, n.b1, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, G1);
+        coop_epilogue<false>(at, bt, 32 * wv, c, h, 0xFFFFu, 1.0f, T1, nullptr);
+        coop_epilogue<true>(ac, bo, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, G1);
     }
     lds_barrier();
     float w3t[8][4], w3c[8][4];
     {   // layer 2 (+ Dropout on the training side, Player.py:194)
+        float bt[16], bo[16];
+        load_bias16(bt, nt.b2, 32 * wv, h); load_bias16(bo, n.b2, 32 * wv, h);
         const f32x16 at = mfma_w<16>(w2t, c, h, T1, 0);
         const f32x16 ac = mfma_w<16>(w2c, c, h, A1, 0);
         load_layer<true, 8>(w3t, nt, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
         load_layer<true, 8>(w3c, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
-        coop_epilogue<false>(at, nt.b2, 32 * wv, c, h, 0xFFFFu, 1.0f, T2, nullptr);
-        coop_epilogue<true>(ac, n.b2, 32 * wv, c, h, dropout_keep_bits(seed, gid, step, wv, h, thr), scale, A2, G2);
+        coop_epilogue<false>(at, bt, 32 * wv, c, h, 0xFFFFu, 1.0f, T2, nullptr);
+        coop_epilogue<true>(ac, bo, 32 * wv, c, h, dropout_keep_bits(seed, gid, step, wv, h, thr), scale, A2, G2);
     }
     lds_barrier();
     float w4t[2][4], w4c[2][4];
     {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197)
+        float bt[16], bo[16];
+        load_bias16(bt, nt.b3, 32 * ot, h); load_bias16(bo, n.b3, 32 * ot, h);
         f32x16 at = mfma_w<8>(w3t, c, h, T2, 64 * half);
         f32x16 ac = mfma_w<8>(w3c, c, h, A2, 64 * half);
         load_layer<true, 2>(w4t, nt, 3, c, h, 16 * wv, 16 * wv + 16);
@@ -558,13 +571,15 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
         if (half == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { at[r] += P[(ot * 16 + r) * 64 + lane]; ac[r] += P2[(ot * 16 + r) * 64 + lane]; }
-            coop_epilogue<false>(at, nt.b3, 32 * ot, c, h, 0xFFFFu, 1.0f, T3, nullptr);
-            coop_epilogue<true>(ac, n.b3, 32 * ot, c, h, dropout_keep_bits(seed, gid, step, 4 + ot, h, thr), scale, A3, G3);
+            coop_epilogue<false>(at, bt, 32 * ot, c, h, 0xFFFFu, 1.0f, T3, nullptr);
+            coop_epilogue<true>(ac, bo, 32 * ot, c, h, dropout_keep_bits(seed, gid, step, 4 + ot, h, thr), scale, A3, G3);
         }
     }
     lds_barrier();
     float w5t[4][4], w5c[4][4];
     {   // layer 4: one output tile, k in quarters
+        float bt[16], bo[16];
+        load_bias16(bt, nt.b4, 0, h); load_bias16(bo, n.b4, 0, h);
         f32x16 at = mfma_w<2>(w4t, c, h, T3, 16 * wv);
         f32x16 ac = mfma_w<2>(w4c, c, h, A3, 16 * wv);
         load_layer<true, 4>(w5t, nt, 4, min(c, n.n_actions - 1), h, 0, wv == 0 ? 32 : 0);
@@ -580,8 +595,8 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
                 at[r] += (P[r * 64 + lane] + P[(16 + r) * 64 + lane]) + P[(32 + r) * 64 + lane];
                 ac[r] += (P2[r * 64 + lane] + P2[(16 + r) * 64 + lane]) + P2[(32 + r) * 64 + lane];
             }
-            coop_epilogue<false>(at, nt.b4, 0, c, h, 0xFFFFu, 1.0f, T4, nullptr);
-            coop_epilogue<true>(ac, n.b4, 0, c, h, 0xFFFFu, 1.0f, A4, G4);
+            coop_epilogue<false>(at, bt, 0, c, h, 0xFFFFu, 1.0f, T4, nullptr);
+            coop_epilogue<true>(ac, bo, 0, c, h, 0xFFFFu, 1.0f, A4, G4);
         }
     }
     lds_barrier();
@@ -749,19 +764,23 @@ constexpr int kSliceStats = kSliceBias + 384, kSlicePitch = kSliceStats + 4;
 // accumulated yet); delta in D, a_{l-1} in Ap; bsum: this tile's db rows of tile ot
 __device__ __forceinline__ void dw_accum(const float* __restrict__ D, const float* __restrict__ Ap, float* __restrict__ slice, int blk,
                                          int ot, int it, int c, int h, bool first, float* bsum) {
-    float ad[16]; float bs = 0.0f;
+    float ad[16], ap[16]; float bs = 0.0f;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) { ad[s2] = D[(32 * ot + c) * kLd + 2 * s2 + h]; bs += ad[s2]; }
+    for (int s2 = 0; s2 < 16; ++s2) { ad[s2] = D[(32 * ot + c) * kLd + 2 * s2 + h]; ap[s2] = Ap[(32 * it + c) * kLd + 2 * s2 + h]; }
+    __builtin_amdgcn_sched_barrier(0);                            // (all 32 LDS reads ahead of the MFMAs, as in mfma_w)
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) bs += ad[s2];
     if (bsum) *bsum += bs + __shfl_xor(bs, 32);
     f32x16 acc = zero16();
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s2], Ap[(32 * it + c) * kLd + 2 * s2 + h], acc, 0, 0, 0);
-    float4* dst = reinterpret_cast<float4*>(slice + (size_t)blk * 1024 + (size_t)(c + 32 * h) * 16);
+    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s2], ap[s2], acc, 0, 0, 0);
+    // registers 4q .. 4q+3 of all 64 lanes form one contiguous KB of the slice: a store instruction writes whole lines
+    float4* dst = reinterpret_cast<float4*>(slice + (size_t)blk * 1024) + (c + 32 * h);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        if (!first) { const float4 o = dst[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        dst[q] = v;
+        if (!first) { const float4 o = dst[64 * q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        dst[64 * q] = v;
     }
 }
 
@@ -780,7 +799,7 @@ __device__ __forceinline__ int slice_param(int j, int K1, int A) {
             if (u >= bias0[l] && u < bias0[l + 1]) return (u - bias0[l]) < n_out[l] ? bbase[l] + (u - bias0[l]) : -1;
         return -1;
     }
-    const int blk = j >> 10, lane = (j >> 4) & 63, r = j & 15, c = lane & 31, h = lane >> 5;
+    const int blk = j >> 10, lane = (j >> 2) & 63, r = 4 * ((j >> 8) & 3) + (j & 3), c = lane & 31, h = lane >> 5;   // [block][q][lane][4]
 #pragma unroll
     for (int l = 0; l < 5; ++l) {
         if (blk >= blk0[l] && blk < blk0[l + 1]) {
@@ -793,24 +812,29 @@ __device__ __forceinline__ int slice_param(int j, int K1, int A) {
 }
 
 // tile `it` of delta_{l-1} = (W^T . delta_l) * g_{l-1} -> Dn[32 it ..]; W is n_out x n_in, delta_l = units [0, KU) of D.
-// The KU / 2 weight loads (one per MFMA, down a column of W) are issued before the first MFMA.
+// back_load: the KU / 2 weights (one per MFMA, down a column of W: coalesced), issued a phase ahead by the caller.
 template <int KU>
-__device__ __forceinline__ void back_block(const float* __restrict__ w, int n_out, int n_in, int it, const float* __restrict__ D,
-                                           const float* __restrict__ G, float* __restrict__ Dn, int c, int h) {
-    float wa[KU / 2];
+__device__ __forceinline__ void back_load(float (&wa)[KU / 2], const float* __restrict__ w, int n_out, int n_in, int it, int c, int h) {
 #pragma unroll
     for (int i = 0; i < KU / 2; ++i) {
         const int k = 2 * i + h;
         wa[i] = k < n_out ? w[(size_t)k * n_in + 32 * it + c] : 0.0f;
     }
+}
+template <int KU>
+__device__ __forceinline__ void back_mul(const float (&wa)[KU / 2], int it, const float* __restrict__ D, const float* __restrict__ G,
+                                         float* __restrict__ Dn, int c, int h) {
+    float dv[KU / 2], gv[16];
+#pragma unroll
+    for (int i = 0; i < KU / 2; ++i) dv[i] = D[(2 * i + h) * kLd + c];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gv[r] = G[(32 * it + rho(r) + 4 * h) * kLd + c];
+    __builtin_amdgcn_sched_barrier(0);                            // (LDS reads ahead of the MFMAs)
     f32x16 acc = zero16();
 #pragma unroll
-    for (int i = 0; i < KU / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], D[(2 * i + h) * kLd + c], acc, 0, 0, 0);
+    for (int i = 0; i < KU / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], dv[i], acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int u = 32 * it + rho(r) + 4 * h;
-        Dn[u * kLd + c] = acc[r] * G[u * kLd + c];
-    }
+    for (int r = 0; r < 16; ++r) Dn[(32 * it + rho(r) + 4 * h) * kLd + c] = acc[r] * gv[r];
 }
 
 template <bool VEC, int NK1>
@@ -890,13 +914,18 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             const int rw = max(rowc, 0);
             const uint64_t gid = a.table_id0 + (uint64_t)rw;
             // both forwards together: target r + gamma * max_a' Q_target(s', a') * (1 - done) (:275-277), network in train mode
-            __syncthreads();
+            lds_barrier();
             QSTAMP(1);
             float w1t[NK1][4], w1c[NK1][4];
             load_layer<VEC, NK1>(w1t, a.tgt, 0, 32 * wv + c, h, 0, (K1 + 7) & ~7);
             load_layer<VEC, NK1>(w1c, n, 0, 32 * wv + c, h, 0, (K1 + 7) & ~7);
             coop_load_rows(lds + CoopLds::Db, a.next_states, a.next_stride, K1, rowc, wv, c, h);
             coop_load_rows(lds + CoopLds::Xs, a.states, a.stride, K1, rowc, wv, c, h);
+            float wb5[16];
+            if (wv == 1) back_load<32>(wb5, n.w5, A, 32, 0, c, h);
+            // the row's transition, ahead of the forwards that need it last
+            const float row_done = (live && a.dones[rw]) ? 1.0f : 0.0f, row_reward = live ? a.rewards[rw] : 0.0f;
+            const int act = live ? (int)a.actions[rw] : -1;
             {
                 f32x16 qn, qv;
                 coop_forward_pair<VEC, NK1>(w1t, w1c, a.tgt, n, lds, wv, c, h, a.seed, gid, a.step, thr, scale, qn, qv);
@@ -906,9 +935,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) if (rho(r) + 4 * h < A) best = fmaxf(best, qn[r]);
                     best = fmaxf(best, __shfl_xor(best, 32));
-                    const float notdone = (live && a.dones[rw]) ? 0.0f : 1.0f;
-                    const float target = (live ? a.rewards[rw] : 0.0f) + a.gamma * best * notdone;
-                    const int act = live ? (int)a.actions[rw] : -1;
+                    const float target = row_reward + a.gamma * best * (1.0f - row_done);
                     float qa = 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) qa += (rho(r) + 4 * h == act) ? qv[r] : 0.0f;
@@ -922,32 +949,40 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
                     rows_sum += cnt; sq_sum += sq;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             QSTAMP(3);
+            // The backward phases talk through LDS only (a wavefront's slice blocks are its own), so their barriers do not wait
+            // for global memory either, and every phase issues the weights of the NEXT phase's delta product first.
             // layer 5 (delta_5 in Da): dW5 | delta_4 -> Db
+            float wb4[16];
+            if (wv >= 2) back_load<32>(wb4, n.w4, 32, 64, wv - 2, c, h);
             if (wv == 0) dw_accum(Da, A4, part_t, kSliceBlk5, 0, 0, c, h, first, &b5);
-            if (wv == 1) back_block<32>(n.w5, A, 32, 0, Da, G4, Db, c, h);
-            __syncthreads();
+            if (wv == 1) back_mul<32>(wb5, 0, Da, G4, Db, c, h);
+            lds_barrier();
             QSTAMP(4);
             // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
+            float wb3[32];
+            back_load<64>(wb3, n.w3, 64, 128, wv, c, h);
             if (wv == 0) dw_accum(Db, A3, part_t, kSliceBlk4 + 0, 0, 0, c, h, first, &b4);
             if (wv == 1) dw_accum(Db, A3, part_t, kSliceBlk4 + 1, 0, 1, c, h, first, nullptr);
-            if (wv >= 2) back_block<32>(n.w4, 32, 64, wv - 2, Db, G3, Da, c, h);
-            __syncthreads();
+            if (wv >= 2) back_mul<32>(wb4, wv - 2, Db, G3, Da, c, h);
+            lds_barrier();
             QSTAMP(5);
             // layer 3 (delta_3 in Da): 8 dW blocks, column tile wv of both row tiles | delta_2 tile wv -> Db
+            float wb2[64];
+            back_load<128>(wb2, n.w2, 128, 128, wv, c, h);
             dw_accum(Da, A2, part_t, kSliceBlk3 + wv, 0, wv, c, h, first, wv == 0 ? &b3 : nullptr);
             dw_accum(Da, A2, part_t, kSliceBlk3 + 4 + wv, 1, wv, c, h, first, wv == 1 ? &b3 : nullptr);
-            back_block<64>(n.w3, 64, 128, wv, Da, G2, Db, c, h);
-            __syncthreads();
+            back_mul<64>(wb3, wv, Da, G2, Db, c, h);
+            lds_barrier();
             QSTAMP(6);
             // layer 2 (delta_2 in Db): 16 dW blocks, column tile wv of each row tile | delta_1 tile wv -> Da
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) dw_accum(Db, A1, part_t, kSliceBlk2 + 4 * ot + wv, ot, wv, c, h, first, ot == wv ? &b2 : nullptr);
             QSTAMP(10);
-            back_block<128>(n.w2, 128, 128, wv, Db, G1, Da, c, h);
+            back_mul<128>(wb2, wv, Db, G1, Da, c, h);
             QSTAMP(11);
-            __syncthreads();
+            lds_barrier();
             QSTAMP(7);
             // layer 1 (delta_1 in Da): row tile wv x the two column tiles of the input
             dw_accum(Da, Xs, part_t, kSliceBlk1 + 2 * wv, wv, 0, c, h, first, &b1);
