@@ -384,6 +384,14 @@ int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride
                    const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
                    uint64_t table_id0, int64_t* actions, float* q_out, const uint8_t* terminated,
                    uint8_t* row_mask_out, void* stream);
+/* The same (seat_idx and row_mask_out required) for a trainer that will call pulse_qnet_train_step / _grads next with
+ * THIS `states` as its states and THIS row_mask_out as its row_mask: the rows that call trains on (row_mask & seat
+ * status ACTIVE / ALLIN) are known already, so their lists are written to the trainer's select_scratch here and the
+ * training call skips its selection launch -- set PulseQNetTrain.select_from_act = 1 for that call (and only that one). */
+int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows,
+                          const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
+                          uint64_t table_id0, int64_t* actions, const uint8_t* terminated, uint8_t* row_mask_out,
+                          int32_t* select_scratch, int64_t select_words, void* stream);
 
 /* PokerQNetwork.train_step (Player.py:255-294) as three launches: (1) row filter + TD target + forward (train mode)
  * + backward on the matrix cores, gradient sums kept in registers and stored once per workgroup; (2) reduction of the
@@ -410,7 +418,8 @@ typedef struct PulseQNetTrain {
     float lr, weight_decay, beta1, beta2, eps, max_grad_norm, gamma, dropout_p;
     int32_t update_freq, max_blocks;
     int32_t* select_scratch;        /* device int32[select_words]: the row-selection launch's lists */
-    int64_t select_words;           /* >= 258 * ceil(n_rows / 256) + 512 for the largest n_rows passed */
+    int64_t select_words;           /* >= 259 * ceil(n_rows / 256) + 512 for the largest n_rows passed */
+    int32_t select_from_act;        /* 1: the lists in select_scratch were written by pulse_qnet_act_select (see there) */
 } PulseQNetTrain;
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions);
 int pulse_qnet_slice_floats(void);

@@ -66,7 +66,7 @@ class QNetTrain(C.Structure):
     _fields_ = [("net", QNet), ("target", QNet)] + [(n, C.c_void_p) for n in (
         "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report", "partials")] + [(n, C.c_float) for n in (
             "lr", "weight_decay", "beta1", "beta2", "eps", "max_grad_norm", "gamma", "dropout_p")] + [
-        ("update_freq", C.c_int32), ("max_blocks", C.c_int32), ("select_scratch", C.c_void_p), ("select_words", C.c_int64)]
+        ("update_freq", C.c_int32), ("max_blocks", C.c_int32), ("select_scratch", C.c_void_p), ("select_words", C.c_int64), ("select_from_act", C.c_int32)]
 
 
 class QTable(C.Structure):
@@ -133,6 +133,7 @@ SYMBOLS = {
     "pulse_particle2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F32, _I32, _P]),
     "pulse_qnet_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "pulse_qnet_act": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P, _P, _P]),
+    "pulse_qnet_act_select": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F32, _U64, _U64, _U64, _P, _P, _P, _P, _I64, _P]),
     "pulse_qnet_param_count": (C.c_int, [_I32, _I32]),
     "pulse_qnet_slice_floats": (C.c_int, []),
     "pulse_qnet_train_step": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I32, _U64, _U64, _U64, _P, _P, _P]),

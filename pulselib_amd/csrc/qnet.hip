@@ -116,6 +116,7 @@ struct QNetArgs {
     int64_t* actions;                                // nullptr: no action selection (plain forward)
     float* q_out;                                    // nullptr or fp32[n_rows, n_actions]
     const uint8_t* terminated; uint8_t* row_mask_out; // masked form only: row_mask_out[r] = selected && !terminated[r]
+    int32_t* tsel_rows; int32_t* tsel_counts;         // nullptr or the training launch's row lists (windows of kActWin rows)
 };
 
 // The network in eval mode on up to 32 rows: lane (c, h) carries the row at `xr` (`live` false = padding column,
@@ -644,7 +645,24 @@ __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
     load_layer<VEC, NK1>(w1r, a.net, 0, 32 * wv + c, h, 0, K1r);           // in flight during the compaction
     float* Bs = lds + CoopLds::P + 3 * 16 * 64;                             // the second network's half of P: free in this kernel
     stage_biases(Bs, a.net);
-    const int count = coop_compact(lds, sel, row);
+    // The rows the NEXT training launch will use (row_mask_out & seat status ACTIVE / ALLIN, Player.py:258-261) are known
+    // here already -- it trains on this observation: their lists are written now and the select launch is not needed.
+    int* tcount = reinterpret_cast<int*>(lds + CoopLds::List) + 260;
+    bool tsel = false; unsigned long long tm = 0ull;
+    if (a.tsel_counts) {
+        tsel = sel && !(a.terminated && a.terminated[row]);
+        if (tsel) { const float status = a.states[(size_t)row * a.row_stride + 12]; tsel = status == 0.0f || status == 2.0f; }
+        tm = __ballot(tsel);
+        if (lane == 0) tcount[wv] = __popcll(tm);
+    }
+    const int count = coop_compact(lds, sel, row);                // (its barriers publish tcount too)
+    if (a.tsel_counts) {
+        int tbase = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tbase += i < wv ? tcount[i] : 0;
+        if (tsel) a.tsel_rows[(size_t)blockIdx.x * WIN + tbase + __popcll(tm & ((1ull << lane) - 1ull))] = row;
+        if (threadIdx.x == 0) a.tsel_counts[blockIdx.x] = (tcount[0] + tcount[1]) + (tcount[2] + tcount[3]);
+    }
     QSTAMP(1);
     const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
     const int A = a.net.n_actions;
@@ -705,7 +723,9 @@ struct TrainArgs {
     const int64_t* actions; const float* rewards;
     const float* next_states; long long next_stride;
     const uint8_t* dones;
-    const int32_t* sel_rows; const int32_t* sel_counts;   // the select launch's lists: sel_rows[256 w + i], i < sel_counts[w]
+    const int32_t* sel_rows; const int32_t* sel_counts;   // the row lists: sel_rows[(w << win_shift) + i], i < sel_counts[w]
+    int win_shift;                                        // 8: the select launch's windows; 7: the act launch's
+    const uint8_t* row_mask; uint8_t* terminated; int book; // book: the per-candidate bookkeeping is done here (lists from act)
     unsigned* meet;
     int n_rows;
     uint64_t seed, step, table_id0;
@@ -864,7 +884,20 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     // The selected rows of the whole batch, in window order, are positions [0, T); every workgroup computes the same
     // exclusive sums of the windows' counts (thread t: windows [t per, (t + 1) per)) and takes the tiles ti = blockIdx.x,
     // + gridDim.x, ... of an even split of [0, T) into n_tiles <= 32-row pieces.
-    const int n_windows = (a.n_rows + 255) / 256, per = (n_windows + 255) / 256;
+    float reward_sum = 0.0f;
+    if (a.book) {                                                // what the select launch does per candidate row, when act made the lists
+        for (int win = blockIdx.x; win * 256 < a.n_rows; win += gridDim.x) {
+            const int row = win * 256 + threadIdx.x;
+            const bool cand = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
+            float rew = cand ? a.rewards[row] : 0.0f;            // episode reward: rows of row_mask, before the status filter (trainGPU.py:96)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) rew += __shfl_xor(rew, off);
+            reward_sum += rew;
+            if (a.terminated && row < a.n_rows && a.dones[row]) a.terminated[row] = 1;      // trainGPU.py:86
+        }
+    }
+    const int W = 1 << a.win_shift;
+    const int n_windows = (a.n_rows + W - 1) >> a.win_shift, per = (n_windows + 255) / 256;
     int* chunk = reinterpret_cast<int*>(lds + CoopLds::List);    // [256] first position of thread t's windows, [256] = T
     int T;
     {
@@ -908,7 +941,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
                 for (int s = 128; s >= 1; s >>= 1) t += (chunk[t + s] <= p) ? s : 0;
                 int w = t * per, acc = chunk[t], cnt = a.sel_counts[w];
                 while (p >= acc + cnt) { acc += cnt; ++w; cnt = a.sel_counts[w]; }
-                rowc = a.sel_rows[(size_t)w * 256 + (p - acc)];
+                rowc = a.sel_rows[((size_t)w << a.win_shift) + (p - acc)];
             }
             const bool live = rowc >= 0;
             const int rw = max(rowc, 0);
@@ -1003,9 +1036,14 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
         part[kSliceBias + 128 + 32 * wv + c0] = b2;
         part[kSliceBias + 32 * wv + c0] = b1;
     }
+    float* wave_reward = lds + CoopLds::Tgt;                      // (32 spare words)
+    lds_barrier();
+    if (lane == 0) wave_reward[wv] = reward_sum;
+    lds_barrier();
     if (wv == 0 && lane == 0) {
         float* ps = part + kSliceStats;
-        ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = 0.0f; ps[3] = used ? 1.0f : 0.0f;
+        ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = (wave_reward[0] + wave_reward[1]) + (wave_reward[2] + wave_reward[3]);
+        ps[3] = used ? 1.0f : 0.0f;
     }
     QSTAMP(9);
 }
@@ -1112,7 +1150,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     if ((FUSED || blockIdx.x == 0) && threadIdx.x < 64) {        // fused: every workgroup totals the row count itself
         for (int b = threadIdx.x; b < a.n_blocks; b += 64) {
             const float* ps = a.partials + b * pitch + kSliceStats;
-            rows += ps[0]; sq += ps[1];
+            rows += ps[0]; sq += ps[1]; rew += (double)ps[2];
         }
         if (blockIdx.x == 0 && a.reward_sum) for (int wdw = threadIdx.x; wdw < a.n_windows; wdw += 64) rew += (double)a.win_reward[wdw];
 #pragma unroll
@@ -1216,9 +1254,34 @@ int pulse_qnet_forward(const PulseQNet* net, const float* states, int64_t row_st
     return launch(a, stream);
 }
 
+namespace {
+int act_call(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows, const int32_t* seat_idx,
+             int32_t q_seat, float epsilon, uint64_t seed, uint64_t step, uint64_t table_id0, int64_t* actions,
+             float* q_out, const uint8_t* terminated, uint8_t* row_mask_out, int32_t* select_scratch, int64_t select_words, void* stream);
+}
+
 int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows, const int32_t* seat_idx,
                    int32_t q_seat, float epsilon, uint64_t seed, uint64_t step, uint64_t table_id0, int64_t* actions,
                    float* q_out, const uint8_t* terminated, uint8_t* row_mask_out, void* stream) {
+    return act_call(net, states, row_stride, n_rows, seat_idx, q_seat, epsilon, seed, step, table_id0, actions, q_out, terminated, row_mask_out,
+                    nullptr, 0, stream);
+}
+
+int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows, const int32_t* seat_idx,
+                          int32_t q_seat, float epsilon, uint64_t seed, uint64_t step, uint64_t table_id0, int64_t* actions,
+                          const uint8_t* terminated, uint8_t* row_mask_out, int32_t* select_scratch, int64_t select_words, void* stream) {
+    if (!select_scratch || !seat_idx || !row_mask_out || !net || net->state_dim < 13 || net->state_dim > 64)
+        return pulse::fail(PULSE_EINVAL, "pulse_qnet_act_select: needs seat_idx, row_mask_out, select_scratch and state_dim 13..64");
+    if (select_words < (int64_t)((n_rows + 255) / 256) * 259 + 512)
+        return pulse::fail(PULSE_EINVAL, "pulse_qnet_act_select: select_scratch must hold 259 words per 256 rows + 512");
+    return act_call(net, states, row_stride, n_rows, seat_idx, q_seat, epsilon, seed, step, table_id0, actions, nullptr, terminated, row_mask_out,
+                    select_scratch, select_words, stream);
+}
+
+namespace {
+int act_call(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows, const int32_t* seat_idx,
+             int32_t q_seat, float epsilon, uint64_t seed, uint64_t step, uint64_t table_id0, int64_t* actions,
+             float* q_out, const uint8_t* terminated, uint8_t* row_mask_out, int32_t* select_scratch, int64_t select_words, void* stream) {
     if (!net || !actions) return pulse::fail(PULSE_EINVAL, "pulse_qnet_act: null argument");
     if (row_mask_out && (!seat_idx || net->state_dim > 64))
         return pulse::fail(PULSE_EINVAL, "pulse_qnet_act: row_mask_out needs seat_idx and state_dim <= 64");
@@ -1226,8 +1289,10 @@ int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride
     a.net = *net; a.states = states; a.row_stride = row_stride; a.n_rows = n_rows; a.seat_idx = seat_idx; a.q_seat = q_seat;
     a.epsilon = epsilon; a.seed = seed; a.step = step; a.table_id0 = table_id0; a.actions = actions; a.q_out = q_out;
     a.terminated = terminated; a.row_mask_out = row_mask_out;
+    if (select_scratch) { a.tsel_rows = select_scratch; a.tsel_counts = select_scratch + (size_t)((n_rows + 255) / 256) * 256; }
     return launch(a, stream);
 }
+}  // namespace
 
 
 #if PULSE_STAMPS
@@ -1293,16 +1358,27 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
         a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
         a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
         a.gamma = t->gamma; a.drop_p = t->dropout_p;
-        const int n_windows = (n_rows + 255) / 256;
-        if (!t->select_scratch || t->select_words < (int64_t)n_windows * 258 + 512)
-            return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: select_scratch must hold 258 words per 256 rows + 512");
-        SelectArgs sa{};
-        sa.states = states; sa.stride = row_stride; sa.rewards = rewards; sa.dones = dones; sa.row_mask = row_mask; sa.terminated = terminated;
-        sa.n_rows = n_rows; sa.sel_rows = t->select_scratch; sa.sel_counts = t->select_scratch + (size_t)n_windows * 256;
-        sa.win_reward = reinterpret_cast<float*>(t->select_scratch + (size_t)n_windows * 257);
-        a.sel_rows = sa.sel_rows; a.sel_counts = sa.sel_counts;
-        a.meet = reinterpret_cast<unsigned*>(t->select_scratch + (size_t)n_windows * 258);
-        hipLaunchKernelGGL(qnet_select_kernel, dim3((unsigned)n_windows), dim3(256), 0, st, sa);
+        // select_scratch (int32 words), nw = ceil(n_rows / 256): [0, 256 nw) row lists; [256 nw, 258 nw) window counts (256-row
+        // windows from the select launch, 128-row windows from pulse_qnet_act_select); [258 nw, 259 nw) window reward sums;
+        // [259 nw, +512) the fused reduce launch's meeting words
+        const int nw = (n_rows + 255) / 256;
+        if (!t->select_scratch || t->select_words < (int64_t)nw * 259 + 512)
+            return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: select_scratch must hold 259 words per 256 rows + 512");
+        int32_t* sel_rows = t->select_scratch; int32_t* sel_counts = t->select_scratch + (size_t)nw * 256;
+        float* win_reward = reinterpret_cast<float*>(t->select_scratch + (size_t)nw * 258);
+        a.sel_rows = sel_rows; a.sel_counts = sel_counts;
+        a.meet = reinterpret_cast<unsigned*>(t->select_scratch + (size_t)nw * 259);
+        int n_windows = 0;                                         // (windows with a reward sum: the select launch's)
+        if (t->select_from_act) {                                  // the lists are pulse_qnet_act_select's, on this observation
+            a.win_shift = 7; a.book = 1; a.row_mask = row_mask; a.terminated = terminated;
+        } else {
+            a.win_shift = 8; a.book = 0;
+            n_windows = nw;
+            SelectArgs sa{};
+            sa.states = states; sa.stride = row_stride; sa.rewards = rewards; sa.dones = dones; sa.row_mask = row_mask; sa.terminated = terminated;
+            sa.n_rows = n_rows; sa.sel_rows = sel_rows; sa.sel_counts = sel_counts; sa.win_reward = win_reward;
+            hipLaunchKernelGGL(qnet_select_kernel, dim3((unsigned)nw), dim3(256), 0, st, sa);
+        }
         const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
         // instances: layer-1 steps 5 (16-byte rows of <= 40 inputs) or 8
         const void* fns[3] = {reinterpret_cast<const void*>(&qnet_train_kernel<false, 8>), reinterpret_cast<const void*>(&qnet_train_kernel<true, 8>),
@@ -1323,7 +1399,7 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
     r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
-    r.reward_sum = reward_sum; r.win_reward = sa.win_reward; r.n_windows = n_windows; r.meet = a.meet;
+    r.reward_sum = reward_sum; r.win_reward = win_reward; r.n_windows = n_windows; r.meet = a.meet;
     fused = apply;                                             // one GPU: AdamW rides in the reduce launch
     AdamArgs b = adam_args(t, np);
     const unsigned rg = (unsigned)((kSliceStats + 127) / 128);

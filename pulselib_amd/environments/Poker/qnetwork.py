@@ -136,10 +136,13 @@ class PokerQNetwork(nn.Module):
                                                    _native.current_stream(states.device)), "pulse_qnet_act")
         return actions
 
-    def act_into(self, states, curr_players, q_seat: int, actions, step_counter=None, terminated=None, row_mask_out=None):
+    def act_into(self, states, curr_players, q_seat: int, actions, step_counter=None, terminated=None, row_mask_out=None,
+                 select_for_training=False):
         """`actions[mask] = self.get_actions(states[mask])` for mask = (curr_players == q_seat) (utils.py:113-119) as one
         launch: rows of other seats are not touched, nothing is gathered, nothing syncs.  `row_mask_out` (bool/uint8[n]):
-        also receives `(curr_players == q_seat) & ~terminated` for every row, the trainer's mask (trainGPU.py:85)."""
+        also receives `(curr_players == q_seat) & ~terminated` for every row, the trainer's mask (trainGPU.py:85).
+        select_for_training: the next train_step_native on these `states` with this row_mask_out skips its row-selection
+        launch (the lists are written here: pulse_qnet_act_select)."""
         self._decay_epsilon()
         states = self._rows(states)
         if actions.dtype != torch.int64 or not actions.is_contiguous():
@@ -148,7 +151,18 @@ class PokerQNetwork(nn.Module):
         self._calls += 1
         step = (1 << 40) + self._calls if step_counter is None else int(step_counter)
         net = self._net_struct(self.network)
-        _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), states.shape[0],
+        n = states.shape[0]
+        self._act_selected = None
+        if select_for_training and row_mask_out is not None and n > 0:
+            self._native_state(n)
+            scratch = self._native["select"]
+            _native.check(_native.lib().pulse_qnet_act_select(
+                C.byref(net), states.data_ptr(), states.stride(0), n, curr.data_ptr(), int(q_seat), float(self.epsilon),
+                self.seed & (2**64 - 1), step, self.table_id0, actions.data_ptr(), None if terminated is None else terminated.data_ptr(),
+                row_mask_out.data_ptr(), scratch.data_ptr(), scratch.numel(), _native.current_stream(states.device)), "pulse_qnet_act_select")
+            self._act_selected = (states.data_ptr(), states.stride(0), row_mask_out.data_ptr(), n)
+            return actions
+        _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), n,
                                                    curr.data_ptr(), int(q_seat), float(self.epsilon), self.seed & (2**64 - 1), step,
                                                    self.table_id0, actions.data_ptr(), None,
                                                    None if terminated is None else terminated.data_ptr(),
@@ -189,7 +203,7 @@ class PokerQNetwork(nn.Module):
                 "partials": torch.empty(TRAIN_BLOCKS * _native.lib().pulse_qnet_slice_floats(), dtype=torch.float32,
                                         device=dev),                                            # 37 MB at 256 workgroups
             }
-        words = 258 * ((max(int(n_rows), 1 << 16) + 255) // 256) + 512        # the row-selection launch's lists (pulse_env.h)
+        words = 259 * ((max(int(n_rows), 1 << 16) + 255) // 256) + 512        # the training launch's row lists (pulse_env.h)
         if nat.get("select") is None or nat["select"].numel() < words:
             nat["select"] = torch.empty(words, dtype=torch.int32, device=self._flat.device)
             self._struct_cache.pop("train", None)
@@ -249,6 +263,11 @@ class PokerQNetwork(nn.Module):
         self._calls += 1
         step = (1 << 41) + self._calls if step_counter is None else int(step_counter)
         lib, stream = _native.lib(), _native.current_stream(states.device)
+        # the row lists act_into(select_for_training=True) wrote serve exactly the call on its states and its mask
+        made = getattr(self, "_act_selected", None)
+        t.select_from_act = int(made is not None and mask8 is not None
+                                and made == (states.data_ptr(), states.stride(0), mask8.data_ptr(), n))
+        self._act_selected = None
         args = (C.byref(t), states.data_ptr(), states.stride(0), actions.data_ptr(), rewards.data_ptr(), next_states.data_ptr(),
                 next_states.stride(0), dones8.data_ptr(), None if mask8 is None else mask8.data_ptr(), n, self.seed & (2**64 - 1), step,
                 self.table_id0, term8, None if reward_sum is None else reward_sum.data_ptr(), stream)

@@ -158,10 +158,11 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
             else:
                 state_before.copy_(state)                                             # the env reuses its obs buffer
             if native:
-                # active_games = q_mask & ~terminated (trainGPU.py:85) comes out of the act launch; `terminated |= dones`
-                # (:86) and the episode reward (:96) ride on the training launches
-                q_agent.act_into(state, seat_idx, q_seat, actions, step_counter=global_step, terminated=terminated,
-                                 row_mask_out=active_games)
+                # active_games = q_mask & ~terminated (trainGPU.py:85) comes out of the act launch, and so do the lists of the
+                # rows the training launch will take (it trains on this very observation); `terminated |= dones` (:86) and
+                # the episode reward (:96) ride on the training launches
+                q_agent.act_into(state_before, seat_idx, q_seat, actions, step_counter=global_step, terminated=terminated,
+                                 row_mask_out=active_games, select_for_training=True)
                 next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
                 if hand_metrics is not None:
                     hand_metrics.update(env, dones, terminated)                       # before terminated |= dones

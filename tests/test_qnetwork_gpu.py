@@ -451,3 +451,39 @@ def test_native_kernels_empty_and_full_selections(g):
     before = _flat(q.network)
     rep = q.train_step_native(s[:0], acts[:0], torch.zeros(0, device=DEV), s[:0], torch.zeros(0, dtype=torch.bool, device=DEV))
     assert np.array_equal(_flat(q.network), before)                                      # zero rows: nothing launched, nothing moves
+
+
+@pytest.mark.parametrize("n", [700, 5000, 70001])
+def test_row_lists_from_the_act_launch_equal_the_selection_launch(g, n):
+    """act_into(select_for_training=True) writes the training launch's row lists (128-row windows) itself; the lists of the
+    selection launch (256-row windows) hold the same rows in the same order, so the two ways train the same tiles and
+    leave bit-identical parameters; `terminated |= dones` equal, the episode reward equal up to its summation order."""
+    rng = np.random.default_rng(n)
+    b = _batch(n, 17)
+    b["states"][:, 12] = rng.integers(0, 4, n)                   # seat status: a good part of the rows is not trainable
+    seat = torch.from_numpy(rng.integers(0, 6, n).astype(np.int32)).to(DEV)
+    term0 = torch.from_numpy(rng.random(n) < 0.15).to(DEV)
+    dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
+    out = []
+    for fold in (False, True):
+        q = _qnet(g, "s40", seed=9)
+        acts = torch.zeros(n, dtype=torch.long, device=DEV)
+        mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+        term = term0.clone()
+        acc = torch.zeros((), dtype=torch.float64, device=DEV)
+        for step in range(3):
+            q.act_into(dev["states"], seat, 2, acts, step_counter=step, terminated=term, row_mask_out=mask, select_for_training=fold)
+            assert (getattr(q, "_act_selected", None) is not None) == fold
+            rep = q.train_step_native(dev["states"], acts, dev["rewards"], dev["next_states"], dev["dones"], mask, step_counter=step,
+                                      terminated=term, reward_sum=acc)
+        out.append((_flat(q.network), rep.cpu().numpy(), term.cpu().numpy(), float(acc), acts.cpu().numpy(), mask.cpu().numpy()))
+    (p0, r0, t0, a0, ac0, m0), (p1, r1, t1, a1, ac1, m1) = out
+    np.testing.assert_array_equal(ac0, ac1); np.testing.assert_array_equal(m0, m1); np.testing.assert_array_equal(t0, t1)
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(r0[:1], r1[:1])
+    assert r0[0] > 0 and abs(a0 - a1) <= 1e-4 * max(1.0, abs(a0))
+    # a training call on other inputs than the act call's does not pick the lists up
+    q.act_into(dev["states"], seat, 2, acts, step_counter=9, terminated=term, row_mask_out=mask, select_for_training=True)
+    other = dev["states"].clone()
+    q.train_step_native(other, acts, dev["rewards"], dev["next_states"], dev["dones"], mask, step_counter=9)
+    assert q._struct_cache["train"].select_from_act == 0
