@@ -419,6 +419,21 @@ __device__ __forceinline__ void coop_epilogue(const f32x16& acc, const float (&b
     }
 }
 
+// the same for accumulator registers 0..7 of `acc` standing for units unit0 + rho(i) + 4h (no dropout)
+template <bool TRAIN>
+__device__ __forceinline__ void coop_epilogue8(const f32x16& acc, const float (&bz)[8], int unit0, int c, int h, float* __restrict__ As,
+                                               float* __restrict__ Gs) {
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        const int u = unit0 + rho(r) + 4 * h;
+        const f32x2 z = {acc[r] + bz[r], acc[r + 1] + bz[r + 1]};
+        f32x2 y, dy;
+        if (PULSE_QABL & 2) { y = z; dy = z; } else gelu_pair2(z, y, dy);
+        As[u * kLd + c] = y.x; As[(u + 1) * kLd + c] = y.y;
+        if (TRAIN) { Gs[u * kLd + c] = dy.x; Gs[(u + 1) * kLd + c] = dy.y; }
+    }
+}
+
 // 32 rows of `x` (row ids per column in `rowc`, < 0 = padding) -> Xs[k][column], zero above state_dim; all 4 wavefronts
 __device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const float* __restrict__ x, long long stride, int K1, int rowc,
                                                int wv, int c, int h) {
@@ -557,48 +572,61 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     }
     lds_barrier();
     float w4t[2][4], w4c[2][4];
-    {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197)
-        float bt[16], bo[16];
-        load_bias16(bt, nt.b3, 32 * ot, h); load_bias16(bo, n.b3, 32 * ot, h);
+    {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197).  The two wavefronts of a tile swap partial sums: the one
+        // with the lower half of k finishes the target network's tile, the other the trained network's (one epilogue each)
+        float bz[16];
+        load_bias16(bz, half == 0 ? nt.b3 : n.b3, 32 * ot, h);
         f32x16 at = mfma_w<8>(w3t, c, h, T2, 64 * half);
         f32x16 ac = mfma_w<8>(w3c, c, h, A2, 64 * half);
         load_layer<true, 2>(w4t, nt, 3, c, h, 16 * wv, 16 * wv + 16);
         load_layer<true, 2>(w4c, n, 3, c, h, 16 * wv, 16 * wv + 16);
-        if (half == 1) {
+        if (half == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { P[(ot * 16 + r) * 64 + lane] = at[r]; P2[(ot * 16 + r) * 64 + lane] = ac[r]; }
+            for (int r = 0; r < 16; ++r) P2[(ot * 16 + r) * 64 + lane] = ac[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[(ot * 16 + r) * 64 + lane] = at[r];
         }
         lds_barrier();
         if (half == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { at[r] += P[(ot * 16 + r) * 64 + lane]; ac[r] += P2[(ot * 16 + r) * 64 + lane]; }
-            coop_epilogue<false>(at, bt, 32 * ot, c, h, 0xFFFFu, 1.0f, T3, nullptr);
-            coop_epilogue<true>(ac, bo, 32 * ot, c, h, dropout_keep_bits(seed, gid, step, 4 + ot, h, thr), scale, A3, G3);
+            for (int r = 0; r < 16; ++r) at[r] += P[(ot * 16 + r) * 64 + lane];
+            coop_epilogue<false>(at, bz, 32 * ot, c, h, 0xFFFFu, 1.0f, T3, nullptr);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ac[r] = P2[(ot * 16 + r) * 64 + lane] + ac[r];
+            coop_epilogue<true>(ac, bz, 32 * ot, c, h, dropout_keep_bits(seed, gid, step, 4 + ot, h, thr), scale, A3, G3);
         }
     }
     lds_barrier();
     float w5t[4][4], w5c[4][4];
-    {   // layer 4: one output tile, k in quarters
-        float bt[16], bo[16];
-        load_bias16(bt, nt.b4, 0, h); load_bias16(bo, n.b4, 0, h);
-        f32x16 at = mfma_w<2>(w4t, c, h, T3, 16 * wv);
-        f32x16 ac = mfma_w<2>(w4c, c, h, A3, 16 * wv);
+    {   // layer 4: one output tile per network, k in quarters.  Group g = (network g >> 1, accumulator registers 8 (g & 1) .. +8)
+        // is finished by wavefront g: the others send it their partial sums of those registers (3 x 8 words per lane and group)
+        const int own_net = wv >> 1, rb = 8 * (wv & 1);
+        float bz8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bz8[i] = (own_net ? n.b4 : nt.b4)[2 * rb + rho(i) + 4 * h];      // units of registers rb + i: rho(i) + 16 (rb / 8) + 4h
+        const f32x16 at = mfma_w<2>(w4t, c, h, T3, 16 * wv);
+        const f32x16 ac = mfma_w<2>(w4c, c, h, A3, 16 * wv);
         load_layer<true, 4>(w5t, nt, 4, min(c, n.n_actions - 1), h, 0, wv == 0 ? 32 : 0);
         load_layer<true, 4>(w5c, n, 4, min(c, n.n_actions - 1), h, 0, wv == 0 ? 32 : 0);
-        if (wv > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { P[((wv - 1) * 16 + r) * 64 + lane] = at[r]; P2[((wv - 1) * 16 + r) * 64 + lane] = ac[r]; }
+        for (int g = 0; g < 4; ++g) {
+            if (g != wv) {
+                const int slot = (wv - g - 1) & 3;                // 0..2
+#pragma unroll
+                for (int i = 0; i < 8; ++i) P[((g * 3 + slot) * 8 + i) * 64 + lane] = (g >> 1) ? ac[8 * (g & 1) + i] : at[8 * (g & 1) + i];
+            }
         }
         lds_barrier();
-        if (wv == 0) {
+        f32x16 fin = zero16();                                     // registers 0..7: this wavefront's group
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                at[r] += (P[r * 64 + lane] + P[(16 + r) * 64 + lane]) + P[(32 + r) * 64 + lane];
-                ac[r] += (P2[r * 64 + lane] + P2[(16 + r) * 64 + lane]) + P2[(32 + r) * 64 + lane];
-            }
-            coop_epilogue<false>(at, bt, 0, c, h, 0xFFFFu, 1.0f, T4, nullptr);
-            coop_epilogue<true>(ac, bo, 0, c, h, 0xFFFFu, 1.0f, A4, G4);
+        for (int i = 0; i < 8; ++i) {
+            const float own = own_net ? (rb ? ac[8 + i] : ac[i]) : (rb ? at[8 + i] : at[i]);
+            fin[i] = own + ((P[((wv * 3 + 0) * 8 + i) * 64 + lane] + P[((wv * 3 + 1) * 8 + i) * 64 + lane]) + P[((wv * 3 + 2) * 8 + i) * 64 + lane]);
         }
+        if (own_net) coop_epilogue8<true>(fin, bz8, 2 * rb, c, h, A4, G4);
+        else coop_epilogue8<false>(fin, bz8, 2 * rb, c, h, T4, nullptr);
     }
     lds_barrier();
     q_tgt = zero16(); q = zero16();
