@@ -434,15 +434,24 @@ __device__ __forceinline__ void coop_epilogue8(const f32x16& acc, const float (&
     }
 }
 
-// 32 rows of `x` (row ids per column in `rowc`, < 0 = padding) -> Xs[k][column], zero above state_dim; all 4 wavefronts
+// 32 rows of `x` (row ids per column in `rowc`, < 0 = padding) -> Xs[k][column], zero above state_dim; all 4 wavefronts.
+// VEC (16-byte aligned rows of a multiple of 8 inputs): a lane's 8 inputs are two 16-byte loads.
+template <bool VEC>
 __device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const float* __restrict__ x, long long stride, int K1, int rowc,
                                                int wv, int c, int h) {
     const float* xr = x + (size_t)max(rowc, 0) * stride;
+    const int k0 = 16 * wv + 8 * h;
+    float v[8];
+    if (VEC) {
+        float4 lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hi = lo;
+        if (rowc >= 0 && k0 < K1) { lo = *reinterpret_cast<const float4*>(xr + k0); hi = *reinterpret_cast<const float4*>(xr + k0 + 4); }
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 16 * wv + 8 * h + j;
-        dst[k * kLd + c] = (rowc >= 0 && k < K1) ? xr[k] : 0.0f;
+        for (int j = 0; j < 8; ++j) v[j] = (rowc >= 0 && k0 + j < K1) ? xr[k0 + j] : 0.0f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[(k0 + j) * kLd + c] = v[j];
 }
 
 // the five bias vectors -> Bs (b1 @0, b2 @128, b3 @256, b4 @320, b5 @352; 384 floats), all threads of the workgroup
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
     for (int t0 = 0; t0 < count; t0 += 32) {
         const int rowc = t0 + c < count ? list[t0 + c] : -1;
         lds_barrier();                                                        // previous tile's readers are done
-        coop_load_rows(lds + CoopLds::Xs, a.states, a.row_stride, K1, rowc, wv, c, h);
+        coop_load_rows<VEC>(lds + CoopLds::Xs, a.states, a.row_stride, K1, rowc, wv, c, h);
         const f32x16 qv = coop_forward_eval<NK1>(w1r, a.net, lds, Bs, wv, c, h);
         if (wv == 0) {
             const bool live = rowc >= 0;
@@ -980,8 +989,8 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             float w1t[NK1][4], w1c[NK1][4];
             load_layer<VEC, NK1>(w1t, a.tgt, 0, 32 * wv + c, h, 0, (K1 + 7) & ~7);
             load_layer<VEC, NK1>(w1c, n, 0, 32 * wv + c, h, 0, (K1 + 7) & ~7);
-            coop_load_rows(lds + CoopLds::Db, a.next_states, a.next_stride, K1, rowc, wv, c, h);
-            coop_load_rows(lds + CoopLds::Xs, a.states, a.stride, K1, rowc, wv, c, h);
+            coop_load_rows<VEC>(lds + CoopLds::Db, a.next_states, a.next_stride, K1, rowc, wv, c, h);
+            coop_load_rows<VEC>(lds + CoopLds::Xs, a.states, a.stride, K1, rowc, wv, c, h);
             float wb5[16];
             if (wv == 1) back_load<32>(wb5, n.w5, A, 32, 0, c, h);
             // the row's transition, ahead of the forwards that need it last
