@@ -393,9 +393,10 @@ int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row
                           uint64_t table_id0, int64_t* actions, const uint8_t* terminated, uint8_t* row_mask_out,
                           int32_t* select_scratch, int64_t select_words, void* stream);
 
-/* PokerQNetwork.train_step (Player.py:255-294) as three launches: (1) row filter + TD target + forward (train mode)
- * + backward on the matrix cores, gradient sums kept in registers and stored once per workgroup; (2) reduction of the
- * workgroups' slices; (3) gradient mean / clip_grad_norm_ / AdamW / target sync, elementwise.
+/* PokerQNetwork.train_step (Player.py:255-294) as up to three launches: (0) the row filter as lists of row ids per
+ * window (skipped when pulse_qnet_act_select wrote them); (1) the listed rows dealt evenly to the workgroups: TD target +
+ * forward (train mode) + backward on the matrix cores, gradient sums accumulated per workgroup; (2) reduction of the
+ * workgroups' slices, then -- in the same launch -- gradient mean / clip_grad_norm_ / AdamW / target sync.
  * The network and its target each live in ONE flat fp32 buffer of pulse_qnet_param_count() floats laid out
  * w1,b1,w2,b2,w3,b3,w4,b4,w5,b5 (torch layouts); `net` / `target` hold the ten views.  grad, exp_avg, exp_avg_sq: flat
  * buffers of the same length (moments zero before the first call).  partials: device fp32[max_blocks *
@@ -408,8 +409,8 @@ int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row
  * NULL = skip) gets terminated[r] |= dones[r]; reward_sum (device double, NULL = skip) += sum of rewards over the
  * row_mask rows (before the status filter).
  * Dropout(.1) after the 2nd and 3rd GELU draws 16-bit uniforms from Philox4x32-10(seed ^ 0xD50F0D50F0, table_id0 + r,
- * 32 * step_counter + unit / 8); dropout_p = 0 disables it.  Sums over rows run in workgroup order: deterministic for
- * a given n_rows and max_blocks. */
+ * 32 * step_counter + unit / 8); dropout_p = 0 disables it.  Sums over rows run in a fixed order: deterministic for
+ * a given n_rows and max_blocks (whichever launch made the row lists). */
 typedef struct PulseQNetTrain {
     PulseQNet net, target;
     float *params, *target_params, *grad, *exp_avg, *exp_avg_sq;

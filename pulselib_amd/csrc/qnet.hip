@@ -737,20 +737,21 @@ __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
 // Launch 1 (qnet_train_kernel) does, for the rows that pass the reference's filters, what train_step does between
 // its masks and `loss.backward()`: TD target from the target network, forward in train mode (dropout after the 2nd
 // and 3rd GELU), d(loss)/d(parameters) -- UNNORMALISED sums (the 1 / #valid-rows of MSELoss, the norm clipping and
-// AdamW follow in launches 2 and 3, which know the global row count).  Per tile of 32 rows, on one CU:
-//   target    cooperative forward of the target network on s', max over actions -> Tgt[row];
-//   forward   cooperative forward of the network on s; every hidden layer leaves a_l and g_l = gelu'(z_l) * dropout
-//             scale in LDS;  delta_5 = 2 (q[action] - target) on the action's row of the output tile;
+// AdamW follow in launch 2, which knows the global row count).  Per tile of <= 32 rows, on one CU:
+//   forwards  the target network on s' (eval) and the network on s (train mode) through the layers together; every hidden
+//             layer leaves a_l and g_l = gelu'(z_l) * dropout scale in LDS;  target = r + gamma max_a' Q_target(s', a'),
+//             delta_5 = 2 (q[action] - target) on the action's row of the output tile;
 //   backward  per layer, dealt to the 4 wavefronts: the 32x32 blocks of dW_l = delta_l . a_{l-1}^T (both operands read
 //             out of LDS with the row index as the MFMA k, 16 MFMAs per block per tile; db_l falls out of the same
 //             reads) and the tiles of delta_{l-1} = (W_l^T . delta_l) * g_{l-1} (A operand = W_l read down its
 //             columns, coalesced).
 // Every wavefront owns the same 8-10 blocks of dW for the whole launch and accumulates them, tile after tile, in its
 // workgroup's private slice of `partials` (plain read-modify-write, L2-resident; the workgroups are persistent: at
-// most `max_blocks` of them stride over the 256-row windows) -- no atomics: float atomics from 8 XCDs onto 32 K
-// shared addresses were 80 % of this kernel's time in the first version.
-// Launch 2 (qnet_grad_reduce_kernel) sums the slices into the flat gradient and its squared norm; launch 3
-// (qnet_adamw_kernel) is mean / clip_grad_norm_ / AdamW / target sync, elementwise over the parameters.
+// most `max_blocks` of them take the tiles of the batch's row lists in turn) -- no atomics: float atomics from 8 XCDs
+// onto 32 K shared addresses were 80 % of this kernel's time in the first version.
+// Launch 2 (qnet_grad_reduce_kernel) sums the slices into the flat gradient and its squared norm and, on one GPU, applies
+// mean / clip_grad_norm_ / AdamW / target sync to the parameters it holds the sums of (qnet_adamw_kernel: the same as a
+// launch of its own, for data-parallel training where an all-reduce comes between the two).
 struct TrainArgs {
     PulseQNet net, tgt;
     float* partials;                          // [gridDim.x][kSlicePitch]: gradient blocks, biases, then {rows, sum td^2, -, used}
@@ -769,7 +770,7 @@ struct TrainArgs {
     float gamma, drop_p;
 };
 
-// Launch 0 (qnet_select_kernel), one workgroup per window of 256 candidate rows: everything train_step and the trainer do
+// Launch 0 (qnet_select_kernel; not needed after pulse_qnet_act_select), one workgroup per window of 256 candidate rows: everything train_step and the trainer do
 // per CANDIDATE row -- the reference's filters (row_mask, seat status ACTIVE / ALLIN, Player.py:258-261) compacted into
 // the window's list of selected rows, `terminated |= dones` (trainGPU.py:86), the window's reward sum over the row_mask
 // rows (trainGPU.py:96).  The training launch then deals the selected rows of the WHOLE batch evenly to its workgroups:
