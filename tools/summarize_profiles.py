@@ -75,10 +75,11 @@ for n in (65536, 1048576):
         out = {
             "tag": tag, "tables_per_launch": n, "steps_per_launch": int(round(spl)), "steps_per_launch_mean": spl, "active_players": mode,
             "kernel_source_sha256_16": SOURCE_SHA, "kernel_sources": list(bench.KERNEL_SOURCES),
-            "kernel": step_row["Name"].split("(")[0],
+            "kernel": step_row["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
             "rocprof_kernel_trace": {"calls": int(step_row["Calls"]), "avg_us": float(step_row["AverageNs"]) / 1e3,
                                      "min_us": float(step_row["MinNs"]) / 1e3, "max_us": float(step_row["MaxNs"]) / 1e3},
-            "other_kernels_avg_us": {kk.split("(")[0][-40:]: float(v["AverageNs"]) / 1e3 for kk, v in rows.items() if STEP not in kk and "poker" in kk},
+            "other_kernels_avg_us": {kk.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][-48:]: float(v["AverageNs"]) / 1e3
+                                     for kk, v in rows.items() if STEP not in kk and "poker" in kk},
             "bench_event_avg_us": bench_line["roofline"]["kernel_us"] if bench_line and bench_line.get("roofline") else None,
             "algorithmic_bytes_per_launch": alg,
             "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "calibration": calibration,
