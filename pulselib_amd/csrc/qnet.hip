@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "pulse_internal.h"
 
@@ -385,15 +386,35 @@ __device__ __forceinline__ f32x16 dense_lds(const float* __restrict__ w, int K, 
 // the critical path).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// A network as the training kernels see it: ONE base pointer into the flat w1,b1,...,w5,b5 buffer (pulse_env.h:
+// PulseQNetTrain -- the host checks that the ten tensors are those views).  Twenty pointers per network in scalar registers
+// were most of the 200 scalar spills of these kernels (a v_readlane per use).
+struct FlatNet { const float* base; int32_t state_dim, n_actions; };
+__device__ __forceinline__ int layer_base(int layer, int K1) {
+    const int base[5] = {0, 128 * K1 + 128, 128 * K1 + 128 + 128 * 128 + 128, 128 * K1 + 128 + 128 * 128 + 128 + 64 * 128 + 64,
+                         128 * K1 + 128 + 128 * 128 + 128 + 64 * 128 + 64 + 32 * 64 + 32};
+    return base[layer];
+}
+__device__ __forceinline__ const float* net_w(const FlatNet& n, int layer) { return n.base + layer_base(layer, n.state_dim); }
+__device__ __forceinline__ const float* net_b(const FlatNet& n, int layer) {
+    const int nw[5] = {128 * n.state_dim, 128 * 128, 64 * 128, 32 * 64, 32 * n.n_actions};
+    return n.base + layer_base(layer, n.state_dim) + nw[layer];
+}
+__device__ __forceinline__ const float* net_w(const PulseQNet& n, int layer) {
+    return layer == 0 ? n.w1 : layer == 1 ? n.w2 : layer == 2 ? n.w3 : layer == 3 ? n.w4 : n.w5;
+}
+__device__ __forceinline__ const float* net_b(const PulseQNet& n, int layer) {
+    return layer == 0 ? n.b1 : layer == 1 ? n.b2 : layer == 2 ? n.b3 : layer == 3 ? n.b4 : n.b5;
+}
+
 // This lane's A operands of layer `layer` (0..4): W[out_row][k0 + 8 i + 4 h + j] from the torch layout.
 // (Tried and dropped: reading them from a transposed copy [in][out] kept in step by the AdamW launch, so that a wavefront's
 // load is two runs of 32 consecutive floats instead of 64 rows x 16 bytes -- no faster, the kernels are not bound by how
 // the weights arrive)
-template <bool VEC, int NK8>
-__device__ __forceinline__ void load_layer(float (&wa)[NK8][4], const PulseQNet& n, int layer, int out_row, int h, int k0, int k1) {
-    const float* w = layer == 0 ? n.w1 : layer == 1 ? n.w2 : layer == 2 ? n.w3 : layer == 3 ? n.w4 : n.w5;
+template <bool VEC, int NK8, class Net>
+__device__ __forceinline__ void load_layer(float (&wa)[NK8][4], const Net& n, int layer, int out_row, int h, int k0, int k1) {
     const int n_in = layer == 0 ? n.state_dim : layer == 1 ? 128 : layer == 2 ? 128 : layer == 3 ? 64 : 32;
-    load_w<VEC, NK8>(wa, w, n_in, out_row, h, k0, k1);
+    load_w<VEC, NK8>(wa, net_w(n, layer), n_in, out_row, h, k0, k1);
 }
 
 // hidden layer epilogue: z = acc + bias -> a = gelu(z) * m to As; TRAIN also g = gelu'(z) * m to Gs (m = dropout keep * scale)
@@ -544,7 +565,7 @@ __device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], 
 // loaded by the caller ahead of its row gather; every layer issues the next layer's weight loads behind its MFMAs and the
 // barriers in here wait for LDS only, so those loads land during the epilogues.  Biases: global (L2) reads.
 template <bool VEC, int NK1>
-__device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], const float (&w1c)[NK1][4], const PulseQNet& nt, const PulseQNet& n,
+__device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], const float (&w1c)[NK1][4], const FlatNet& nt, const FlatNet& n,
                                                   float* __restrict__ lds, int wv, int c, int h, uint64_t seed, uint64_t gid, uint64_t step,
                                                   uint32_t thr, float scale, f32x16& q_tgt, f32x16& q) {
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
@@ -559,7 +580,7 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     {   // layer 1 (each phase: this layer's biases, the MFMAs, the next layer's weights, the epilogues -- a wait for the
         // biases then never includes the younger weight loads)
         float bt[16], bo[16];
-        load_bias16(bt, nt.b1, 32 * wv, h); load_bias16(bo, n.b1, 32 * wv, h);
+        load_bias16(bt, net_b(nt, 0), 32 * wv, h); load_bias16(bo, net_b(n, 0), 32 * wv, h);
         const f32x16 at = mfma_w<NK1>(w1t, c, h, Xn, 0);
         const f32x16 ac = mfma_w<NK1>(w1c, c, h, Xs, 0);
         load_layer<true, 16>(w2t, nt, 1, 32 * wv + c, h, 0, 128);
@@ -571,7 +592,7 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     float w3t[8][4], w3c[8][4];
     {   // layer 2 (+ Dropout on the training side, Player.py:194)
         float bt[16], bo[16];
-        load_bias16(bt, nt.b2, 32 * wv, h); load_bias16(bo, n.b2, 32 * wv, h);
+        load_bias16(bt, net_b(nt, 1), 32 * wv, h); load_bias16(bo, net_b(n, 1), 32 * wv, h);
         const f32x16 at = mfma_w<16>(w2t, c, h, T1, 0);
         const f32x16 ac = mfma_w<16>(w2c, c, h, A1, 0);
         load_layer<true, 8>(w3t, nt, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
@@ -584,7 +605,7 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     {   // layer 3: 2 output tiles x 2 halves of k (+ Dropout, :197).  The two wavefronts of a tile swap partial sums: the one
         // with the lower half of k finishes the target network's tile, the other the trained network's (one epilogue each)
         float bz[16];
-        load_bias16(bz, half == 0 ? nt.b3 : n.b3, 32 * ot, h);
+        load_bias16(bz, half == 0 ? net_b(nt, 2) : net_b(n, 2), 32 * ot, h);
         f32x16 at = mfma_w<8>(w3t, c, h, T2, 64 * half);
         f32x16 ac = mfma_w<8>(w3c, c, h, A2, 64 * half);
         load_layer<true, 2>(w4t, nt, 3, c, h, 16 * wv, 16 * wv + 16);
@@ -614,7 +635,7 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
         const int own_net = wv >> 1, rb = 8 * (wv & 1);
         float bz8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bz8[i] = (own_net ? n.b4 : nt.b4)[2 * rb + rho(i) + 4 * h];      // units of registers rb + i: rho(i) + 16 (rb / 8) + 4h
+        for (int i = 0; i < 8; ++i) bz8[i] = (own_net ? net_b(n, 3) : net_b(nt, 3))[2 * rb + rho(i) + 4 * h];      // units of registers rb + i: rho(i) + 16 (rb / 8) + 4h
         const f32x16 at = mfma_w<2>(w4t, c, h, T3, 16 * wv);
         const f32x16 ac = mfma_w<2>(w4c, c, h, A3, 16 * wv);
         load_layer<true, 4>(w5t, nt, 4, min(c, n.n_actions - 1), h, 0, wv == 0 ? 32 : 0);
@@ -641,9 +662,9 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     q_tgt = zero16(); q = zero16();
     if (wv == 0) {
         q_tgt = mfma_w<4>(w5t, c, h, T4, 0);
-        bias_act<false>(q_tgt, nt.b5, 0, n.n_actions, h);
+        bias_act<false>(q_tgt, net_b(nt, 4), 0, n.n_actions, h);
         q = mfma_w<4>(w5c, c, h, A4, 0);
-        bias_act<false>(q, n.b5, 0, n.n_actions, h);
+        bias_act<false>(q, net_b(n, 4), 0, n.n_actions, h);
     }
 }
 
@@ -651,7 +672,7 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
 __device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, int row) {
     int* list = reinterpret_cast<int*>(lds + CoopLds::List);
     int* wcount = list + 256;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(sel);
     if (lane == 0) wcount[wv] = __popcll(m);
     __syncthreads();
@@ -670,7 +691,7 @@ __device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, i
 template <bool VEC, int WIN, int NK1>
 __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
     extern __shared__ float lds[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * WIN + threadIdx.x;
     const bool cand = threadIdx.x < WIN && row < a.n_rows;
     const bool sel = cand && a.seat_idx[row] == a.q_seat;
@@ -753,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
 // mean / clip_grad_norm_ / AdamW / target sync to the parameters it holds the sums of (qnet_adamw_kernel: the same as a
 // launch of its own, for data-parallel training where an all-reduce comes between the two).
 struct TrainArgs {
-    PulseQNet net, tgt;
+    FlatNet net, tgt;
     float* partials;                          // [gridDim.x][kSlicePitch]: gradient blocks, biases, then {rows, sum td^2, -, used}
     float* scal;                              // scal[0] = squared gradient norm of the reduce launch: cleared here for it
     int n_params;
@@ -785,7 +806,7 @@ struct SelectArgs {
 __global__ __launch_bounds__(256) void qnet_select_kernel(const SelectArgs a) {
     __shared__ int wcount[4];
     __shared__ float wrew[4];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = blockIdx.x * 256 + threadIdx.x;
     bool sel = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
     float rew = sel ? a.rewards[row] : 0.0f;                     // episode reward: rows of row_mask, before the status filter
@@ -898,8 +919,8 @@ __device__ __forceinline__ void back_mul(const float (&wa)[KU / 2], int it, cons
 template <bool VEC, int NK1>
 __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     extern __shared__ float lds[];
-    const PulseQNet& n = a.net;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane & 31, h0 = lane >> 5;
+    const FlatNet& n = a.net;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c0 = lane & 31, h0 = lane >> 5;
     const int K1 = n.state_dim, A = n.n_actions;
     float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
     float* A4 = lds + CoopLds::A4;
@@ -993,7 +1014,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             coop_load_rows<VEC>(lds + CoopLds::Db, a.next_states, a.next_stride, K1, rowc, wv, c, h);
             coop_load_rows<VEC>(lds + CoopLds::Xs, a.states, a.stride, K1, rowc, wv, c, h);
             float wb5[16];
-            if (wv == 1) back_load<32>(wb5, n.w5, A, 32, 0, c, h);
+            if (wv == 1) back_load<32>(wb5, net_w(n, 4), A, 32, 0, c, h);
             // the row's transition, ahead of the forwards that need it last
             const float row_done = (live && a.dones[rw]) ? 1.0f : 0.0f, row_reward = live ? a.rewards[rw] : 0.0f;
             const int act = live ? (int)a.actions[rw] : -1;
@@ -1026,14 +1047,14 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             // for global memory either, and every phase issues the weights of the NEXT phase's delta product first.
             // layer 5 (delta_5 in Da): dW5 | delta_4 -> Db
             float wb4[16];
-            if (wv >= 2) back_load<32>(wb4, n.w4, 32, 64, wv - 2, c, h);
+            if (wv >= 2) back_load<32>(wb4, net_w(n, 3), 32, 64, wv - 2, c, h);
             if (wv == 0) dw_accum(Da, A4, part_t, kSliceBlk5, 0, 0, c, h, first, &b5);
             if (wv == 1) back_mul<32>(wb5, 0, Da, G4, Db, c, h);
             lds_barrier();
             QSTAMP(4);
             // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
             float wb3[32];
-            back_load<64>(wb3, n.w3, 64, 128, wv, c, h);
+            back_load<64>(wb3, net_w(n, 2), 64, 128, wv, c, h);
             if (wv == 0) dw_accum(Db, A3, part_t, kSliceBlk4 + 0, 0, 0, c, h, first, &b4);
             if (wv == 1) dw_accum(Db, A3, part_t, kSliceBlk4 + 1, 0, 1, c, h, first, nullptr);
             if (wv >= 2) back_mul<32>(wb4, wv - 2, Db, G3, Da, c, h);
@@ -1041,7 +1062,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
             QSTAMP(5);
             // layer 3 (delta_3 in Da): 8 dW blocks, column tile wv of both row tiles | delta_2 tile wv -> Db
             float wb2[64];
-            back_load<128>(wb2, n.w2, 128, 128, wv, c, h);
+            back_load<128>(wb2, net_w(n, 1), 128, 128, wv, c, h);
             dw_accum(Da, A2, part_t, kSliceBlk3 + wv, 0, wv, c, h, first, wv == 0 ? &b3 : nullptr);
             dw_accum(Da, A2, part_t, kSliceBlk3 + 4 + wv, 1, wv, c, h, first, wv == 1 ? &b3 : nullptr);
             back_mul<64>(wb3, wv, Da, G2, Db, c, h);
@@ -1081,6 +1102,287 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     if (wv == 0 && lane == 0) {
         float* ps = part + kSliceStats;
         ps[0] = rows_sum; ps[1] = sq_sum; ps[2] = (wave_reward[0] + wave_reward[1]) + (wave_reward[2] + wave_reward[3]);
+        ps[3] = used ? 1.0f : 0.0f;
+    }
+    QSTAMP(9);
+}
+
+// ---- the same launch with EIGHT wavefronts per workgroup --------------------------------------------------------------
+// One wavefront per SIMD issues roughly one instruction per 8 cycles, and two thirds of the four-wavefront kernel above is
+// instructions that are neither MFMA nor GELU.  Here every SIMD has two wavefronts to issue from: in the
+// forwards wavefronts 0-3 take the target network through its layers and 4-7 the trained network (each as the act kernel's
+// four do, the epilogues of layers 3 and 4 split between them); the backward phases deal their 16 + 4 products per layer to
+// all eight (delta tiles on 0-3, the weight-gradient blocks on 4-7, equal MFMA counts).  Same tiles, same LDS image, same
+// slice layout; a block of the slice is still owned by one wavefront for the whole launch.
+template <bool TRAIN, int NR>
+__device__ __forceinline__ void coop_epilogue_n(const float (&v)[NR], const float (&bz)[NR], int unit0, int c, int h, uint32_t keep, float scale,
+                                                float* __restrict__ As, float* __restrict__ Gs) {
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) {                             // values r, r + 1 are units u, u + 1 (rho(i) = i below 4)
+        const int u = unit0 + rho(r) + 4 * h;
+        const f32x2 z = {v[r] + bz[r], v[r + 1] + bz[r + 1]};
+        const f32x2 m = {((keep >> r) & 1u) ? scale : 0.0f, ((keep >> (r + 1)) & 1u) ? scale : 0.0f};
+        f32x2 y, dy;
+        if (PULSE_QABL & 2) { y = z; dy = z; } else gelu_pair2(z, y, dy);
+        y = y * m;
+        As[u * kLd + c] = y.x; As[(u + 1) * kLd + c] = y.y;
+        if (TRAIN) { dy = dy * m; Gs[u * kLd + c] = dy.x; Gs[(u + 1) * kLd + c] = dy.y; }
+    }
+}
+
+// One network on the 32 rows in X, on the four wavefronts wq = 0..3 of a group; B1..B4 receive a_1..a_4 (G1..G4: g_1..g_4
+// when TRAIN), P is the group's 3072 floats of exchange space.  Returns the output tile in wavefront wq = 0.  7 barriers.
+template <bool TRAIN, int NK1>
+__device__ __forceinline__ f32x16 group_forward(const float (&w1r)[NK1][4], const FlatNet& n, const float* __restrict__ X,
+                                                float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ B3, float* __restrict__ B4,
+                                                float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3, float* __restrict__ G4,
+                                                float* __restrict__ P, int wq, int c, int h, uint64_t seed, uint64_t gid, uint64_t step,
+                                                uint32_t thr, float scale) {
+    const int lane = c + 32 * h, ot = wq & 1, half = wq >> 1, A = n.n_actions;
+    lds_barrier();                                                            // X complete
+    float w2r[16][4];
+    {   // layer 1
+        float bz[16];
+        load_bias16(bz, net_b(n, 0), 32 * wq, h);
+        const f32x16 acc = mfma_w<NK1>(w1r, c, h, X, 0);
+        load_layer<true, 16>(w2r, n, 1, 32 * wq + c, h, 0, 128);
+        coop_epilogue<TRAIN>(acc, bz, 32 * wq, c, h, 0xFFFFu, 1.0f, B1, G1);
+    }
+    lds_barrier();
+    float w3r[8][4];
+    {   // layer 2 (+ Dropout when TRAIN, Player.py:194)
+        float bz[16];
+        load_bias16(bz, net_b(n, 1), 32 * wq, h);
+        const f32x16 acc = mfma_w<16>(w2r, c, h, B1, 0);
+        load_layer<true, 8>(w3r, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
+        coop_epilogue<TRAIN>(acc, bz, 32 * wq, c, h, TRAIN ? dropout_keep_bits(seed, gid, step, wq, h, thr) : 0xFFFFu, TRAIN ? scale : 1.0f, B2, G2);
+    }
+    lds_barrier();
+    float w4r[2][4];
+    {   // layer 3: 2 output tiles x 2 halves of k; the two wavefronts of a tile finish 8 accumulator registers each (+ Dropout, :197)
+        float bz8[8], own[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bz8[i] = net_b(n, 2)[32 * ot + 16 * half + rho(i) + 4 * h];
+        const f32x16 acc = mfma_w<8>(w3r, c, h, B2, 64 * half);
+        load_layer<true, 2>(w4r, n, 3, c, h, 16 * wq, 16 * wq + 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) P[((ot * 2 + (1 - half)) * 8 + i) * 64 + lane] = half ? acc[i] : acc[8 + i];     // the partner's registers
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) own[i] = (half ? acc[8 + i] : acc[i]) + P[((ot * 2 + half) * 8 + i) * 64 + lane];
+        const uint32_t keep = TRAIN ? (dropout_keep_bits(seed, gid, step, 4 + ot, h, thr) >> (8 * half)) : 0xFFFFu;
+        coop_epilogue_n<TRAIN, 8>(own, bz8, 32 * ot + 16 * half, c, h, keep, TRAIN ? scale : 1.0f, B3, G3);
+    }
+    lds_barrier();
+    float w5r[4][4];
+    {   // layer 4: one output tile, k in quarters; wavefront wq finishes registers 4 wq .. 4 wq + 3 (units 8 wq + i + 4h)
+        float bz4[4], own[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bz4[i] = net_b(n, 3)[8 * wq + i + 4 * h];
+        const f32x16 acc = mfma_w<2>(w4r, c, h, B3, 16 * wq);
+        load_layer<true, 4>(w5r, n, 4, min(c, A - 1), h, 0, wq == 0 ? 32 : 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g != wq) {
+                const int slot = (wq - g - 1) & 3;                // 0..2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) P[((g * 3 + slot) * 4 + i) * 64 + lane] = acc[4 * g + i];
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float mine = wq == 0 ? acc[i] : wq == 1 ? acc[4 + i] : wq == 2 ? acc[8 + i] : acc[12 + i];
+            own[i] = mine + ((P[((wq * 3 + 0) * 4 + i) * 64 + lane] + P[((wq * 3 + 1) * 4 + i) * 64 + lane]) + P[((wq * 3 + 2) * 4 + i) * 64 + lane]);
+        }
+        coop_epilogue_n<TRAIN, 4>(own, bz4, 8 * wq, c, h, 0xFFFFu, 1.0f, B4, G4);
+    }
+    lds_barrier();
+    f32x16 qv = zero16();
+    if (wq == 0) {
+        qv = mfma_w<4>(w5r, c, h, B4, 0);
+        bias_act<false>(qv, net_b(n, 4), 0, A, h);
+    }
+    return qv;
+}
+
+template <bool VEC, int NK1>
+__global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
+    extern __shared__ float lds[];
+    const FlatNet& n = a.net;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c0 = lane & 31, h0 = lane >> 5;
+    const int K1 = n.state_dim, A = n.n_actions;
+    float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
+    float* A4 = lds + CoopLds::A4; float* P = lds + CoopLds::P;
+    float* G1 = lds + CoopLds::G1; float* G2 = lds + CoopLds::G2; float* G3 = lds + CoopLds::G3; float* G4 = lds + CoopLds::G4;
+    float* Da = lds + CoopLds::Da; float* Db = lds + CoopLds::Db; float* Tg = lds + CoopLds::Tgt;
+    const uint32_t thr = (uint32_t)(a.drop_p * 65536.0f);
+    const float scale = 1.0f / (1.0f - a.drop_p);
+
+    float b5 = 0.0f, b4 = 0.0f, b3 = 0.0f, b2 = 0.0f, b1 = 0.0f;  // this wavefront's rows of db (see the stores at the end)
+    float rows_sum = 0.0f, sq_sum = 0.0f;                        // wavefront 4
+    bool used = false;
+    float* part = a.partials + (size_t)blockIdx.x * kSlicePitch;
+    if (blockIdx.x == 0 && threadIdx.x < 8) a.meet[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[0] = 0.0f;
+    QSTAMP(0);
+    float reward_sum = 0.0f;
+    if (a.book) {
+        for (int win = blockIdx.x; win * 512 < a.n_rows; win += gridDim.x) {
+            const int row = win * 512 + threadIdx.x;
+            const bool cand = row < a.n_rows && (a.row_mask == nullptr || a.row_mask[row] != 0);
+            float rew = cand ? a.rewards[row] : 0.0f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) rew += __shfl_xor(rew, off);
+            reward_sum += rew;
+            if (a.terminated && row < a.n_rows && a.dones[row]) a.terminated[row] = 1;
+        }
+    }
+    const int W = 1 << a.win_shift;
+    const int n_windows = (a.n_rows + W - 1) >> a.win_shift, per = (n_windows + 255) / 256;
+    int* chunk = reinterpret_cast<int*>(lds + CoopLds::List);
+    int T;
+    {
+        int mine = 0;
+        if (threadIdx.x < 256) for (int j = 0; j < per; ++j) { const int w = threadIdx.x * per + j; mine += w < n_windows ? a.sel_counts[w] : 0; }
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); incl += lane >= off ? o : 0; }
+        int* wtot = chunk + 257;
+        if (lane == 63 && wv < 4) wtot[wv] = incl;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base += i < wv ? wtot[i] : 0;
+        if (threadIdx.x < 256) chunk[threadIdx.x] = base + incl - mine;
+        T = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+        __syncthreads();
+    }
+    const int G = (int)gridDim.x;
+    const int r_tile = min(32, max(8, (T + G - 1) / G));
+    const int n_tiles = (T + r_tile - 1) / r_tile;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
+        const bool first = !used;
+        used = true;
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        float* part_t = part + opaque;
+        int c = c0, h = h0;
+        asm volatile("" : "+v"(c), "+v"(h));
+        const int wq = wv & 3, grp = wv >> 2;
+        const int lo = (int)((long long)ti * T / n_tiles), hi = (int)((long long)(ti + 1) * T / n_tiles);
+        int rowc = -1;
+        if (lo + c < hi) {
+            const int p = lo + c;
+            int t = 0;
+#pragma unroll
+            for (int s = 128; s >= 1; s >>= 1) t += (chunk[t + s] <= p) ? s : 0;
+            int w = t * per, acc = chunk[t], cnt = a.sel_counts[w];
+            while (p >= acc + cnt) { acc += cnt; ++w; cnt = a.sel_counts[w]; }
+            rowc = a.sel_rows[((size_t)w << a.win_shift) + (p - acc)];
+        }
+        const bool live = rowc >= 0;
+        const int rw = max(rowc, 0);
+        const uint64_t gid = a.table_id0 + (uint64_t)rw;
+        lds_barrier();                                            // the previous tile's readers are done
+        QSTAMP(1);
+        // group 0: the target network on s' (x' and a'_2, a'_4 in Db, a'_1 and a'_3 in Da); group 1: the network on s
+        float w1r[NK1][4];
+        load_layer<VEC, NK1>(w1r, grp ? n : a.tgt, 0, 32 * wq + c, h, 0, (K1 + 7) & ~7);
+        if (grp) coop_load_rows<VEC>(Xs, a.states, a.stride, K1, rowc, wq, c, h);
+        else coop_load_rows<VEC>(Db, a.next_states, a.next_stride, K1, rowc, wq, c, h);
+        const float row_done = (live && a.dones[rw]) ? 1.0f : 0.0f, row_reward = live ? a.rewards[rw] : 0.0f;
+        const int act = live ? (int)a.actions[rw] : -1;
+        f32x16 qv;
+        if (grp) qv = group_forward<true, NK1>(w1r, n, Xs, A1, A2, A3, A4, G1, G2, G3, G4, P + 3 * 16 * 64, wq, c, h, a.seed, gid, a.step, thr, scale);
+        else qv = group_forward<false, NK1>(w1r, a.tgt, Db, Da, Db, Da, Db, nullptr, nullptr, nullptr, nullptr, P, wq, c, h, 0, 0, 0, 0, 1.0f);
+        QSTAMP(2);
+        if (wv == 0) {                                            // max_a' Q_target(s', a') per row -> Tg
+            float best = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (rho(r) + 4 * h < A) best = fmaxf(best, qv[r]);
+            best = fmaxf(best, __shfl_xor(best, 32));
+            if (h == 0) Tg[c] = best;
+        }
+        lds_barrier();
+        if (wv == 4) {                                            // delta_5 and the loss terms (:270-279)
+            const float target = row_reward + a.gamma * Tg[c] * (1.0f - row_done);
+            float qa = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa += (rho(r) + 4 * h == act) ? qv[r] : 0.0f;
+            qa += __shfl_xor(qa, 32);
+            const float td = live ? qa - target : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Da[(rho(r) + 4 * h) * kLd + c] = (rho(r) + 4 * h == act) ? 2.0f * td : 0.0f;
+            float sq = (h == 0) ? td * td : 0.0f, cnt = (h == 0 && live) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { sq += __shfl_xor(sq, off); cnt += __shfl_xor(cnt, off); }
+            rows_sum += cnt; sq_sum += sq;
+        }
+        lds_barrier();
+        QSTAMP(3);
+        // layer 5 (delta_5 in Da): dW5 on wavefront 0 | delta_4 -> Db on wavefront 1
+        // (each delta product loads its weights at the start of its own phase: the other wavefront of the SIMD covers the wait,
+        // and weights held a phase ahead do not fit 256 registers next to the phase's own operands)
+        if (wv == 0) dw_accum(Da, A4, part_t, kSliceBlk5, 0, 0, c, h, first, &b5);
+        if (wv == 1) { float wb5[16]; back_load<32>(wb5, net_w(n, 4), A, 32, 0, c, h); back_mul<32>(wb5, 0, Da, G4, Db, c, h); }
+        lds_barrier();
+        QSTAMP(4);
+        // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
+        if (wv == 0) dw_accum(Db, A3, part_t, kSliceBlk4 + 0, 0, 0, c, h, first, &b4);
+        if (wv == 1) dw_accum(Db, A3, part_t, kSliceBlk4 + 1, 0, 1, c, h, first, nullptr);
+        if (wv == 2 || wv == 3) { float wb4[16]; back_load<32>(wb4, net_w(n, 3), 32, 64, wv - 2, c, h); back_mul<32>(wb4, wv - 2, Db, G3, Da, c, h); }
+        lds_barrier();
+        QSTAMP(5);
+        // layer 3 (delta_3 in Da): delta_2 tile wv -> Db on wavefronts 0-3 | dW3 block (row tile j >> 1, column tiles 2 (j & 1), + 1) on 4 + j
+        if (wv < 4) {
+            float wb3[32];
+            back_load<64>(wb3, net_w(n, 2), 64, 128, wv, c, h);
+            back_mul<64>(wb3, wv, Da, G2, Db, c, h);
+        } else {
+            const int j = wv - 4, rt = j >> 1, ct = 2 * (j & 1);
+            dw_accum(Da, A2, part_t, kSliceBlk3 + 4 * rt + ct, rt, ct, c, h, first, (j & 1) == 0 ? &b3 : nullptr);
+            dw_accum(Da, A2, part_t, kSliceBlk3 + 4 * rt + ct + 1, rt, ct + 1, c, h, first, nullptr);
+        }
+        lds_barrier();
+        QSTAMP(6);
+        // layer 2 (delta_2 in Db): delta_1 tile wv -> Da on wavefronts 0-3 | the four dW2 blocks of row tile j on 4 + j
+        if (wv < 4) {
+            float wb2[64];
+            back_load<128>(wb2, net_w(n, 1), 128, 128, wv, c, h);
+            back_mul<128>(wb2, wv, Db, G1, Da, c, h);
+        } else {
+            const int j = wv - 4;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) dw_accum(Db, A1, part_t, kSliceBlk2 + 4 * j + it, j, it, c, h, first, it == 0 ? &b2 : nullptr);
+        }
+        lds_barrier();
+        QSTAMP(7);
+        // layer 1 (delta_1 in Da): block (row tile wv >> 1, input column tile wv & 1) per wavefront
+        if ((wv & 1) == 0 || K1 > 32) dw_accum(Da, Xs, part_t, kSliceBlk1 + wv, wv >> 1, wv & 1, c, h, first, (wv & 1) == 0 ? &b1 : nullptr);
+    }
+
+    QSTAMP(8);
+    if (!used) {
+        for (int i = threadIdx.x; i < kSliceStats; i += 512) part[i] = 0.0f;
+    } else if (K1 <= 32) {                                        // the second column tile of layer 1 was never touched
+        for (int i = threadIdx.x; i < 4 * 1024; i += 512) part[(size_t)(kSliceBlk1 + 2 * (i >> 10) + 1) * 1024 + (i & 1023)] = 0.0f;
+    }
+    if (used && h0 == 0) {                                        // db rows: every bias is written by exactly one wavefront
+        if (wv == 0) { part[kSliceBias + 352 + c0] = b5; part[kSliceBias + 320 + c0] = b4; }
+        if (wv == 4 || wv == 6) part[kSliceBias + 256 + 32 * ((wv - 4) >> 1) + c0] = b3;
+        if (wv >= 4) part[kSliceBias + 128 + 32 * (wv - 4) + c0] = b2;
+        if ((wv & 1) == 0) part[kSliceBias + 32 * (wv >> 1) + c0] = b1;
+    }
+    float* wave_reward = Tg;                                      // (32 spare words)
+    lds_barrier();
+    if (lane == 0) wave_reward[wv] = reward_sum;
+    if (wv == 4 && lane == 0) { wave_reward[8] = rows_sum; wave_reward[9] = sq_sum; }
+    lds_barrier();
+    if (wv == 0 && lane == 0) {
+        float* ps = part + kSliceStats;
+        ps[0] = wave_reward[8]; ps[1] = wave_reward[9];
+        ps[2] = ((wave_reward[0] + wave_reward[1]) + (wave_reward[2] + wave_reward[3])) + ((wave_reward[4] + wave_reward[5]) + (wave_reward[6] + wave_reward[7]));
         ps[3] = used ? 1.0f : 0.0f;
     }
     QSTAMP(9);
@@ -1392,7 +1694,7 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     bool fused = false;
     if (grads && n_rows > 0) {
         TrainArgs a{};
-        a.net = t->net; a.tgt = t->target; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
+        a.net = FlatNet{t->params, n.state_dim, n.n_actions}; a.tgt = FlatNet{t->target_params, n.state_dim, n.n_actions}; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
         a.actions = actions; a.rewards = rewards; a.next_states = next_states; a.next_stride = next_stride; a.dones = dones;
         a.n_rows = n_rows; a.seed = seed; a.step = step_counter; a.table_id0 = table_id0;
         a.gamma = t->gamma; a.drop_p = t->dropout_p;
@@ -1418,20 +1720,22 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
             hipLaunchKernelGGL(qnet_select_kernel, dim3((unsigned)nw), dim3(256), 0, st, sa);
         }
         const bool vec = n.state_dim % 8 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states);
-        // instances: layer-1 steps 5 (16-byte rows of <= 40 inputs) or 8
-        const void* fns[3] = {reinterpret_cast<const void*>(&qnet_train_kernel<false, 8>), reinterpret_cast<const void*>(&qnet_train_kernel<true, 8>),
-                              reinterpret_cast<const void*>(&qnet_train_kernel<true, 5>)};
-        const int slot = vec ? (n.state_dim <= 40 ? 2 : 1) : 0;
-        static const void* attr_set[3] = {nullptr, nullptr, nullptr};
+        // instances: layer-1 steps 5 (16-byte rows of <= 40 inputs) or 8; four or eight wavefronts per tile
+        static const bool four = [] { const char* e = getenv("PULSE_TRAIN_WAVES"); return e && e[0] == '4'; }();
+        const void* fns[6] = {reinterpret_cast<const void*>(&qnet_train_kernel<false, 8>), reinterpret_cast<const void*>(&qnet_train_kernel<true, 8>),
+                              reinterpret_cast<const void*>(&qnet_train_kernel<true, 5>), reinterpret_cast<const void*>(&qnet_train8_kernel<false, 8>),
+                              reinterpret_cast<const void*>(&qnet_train8_kernel<true, 8>), reinterpret_cast<const void*>(&qnet_train8_kernel<true, 5>)};
+        const int slot = (vec ? (n.state_dim <= 40 ? 2 : 1) : 0) + (four ? 0 : 3);
+        static const void* attr_set[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (attr_set[slot] != fns[slot]) {
             const hipError_t e = hipFuncSetAttribute(fns[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsBytes);
             if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
             attr_set[slot] = fns[slot];
         }
-        // persistent workgroups (4 wavefronts, 157 KB of LDS: one per CU); a tile holds at least 8 selected rows
+        // persistent workgroups (157 KB of LDS: one per CU); a tile holds at least 8 selected rows
         const int grid = std::min((n_rows + 7) / 8, (int)t->max_blocks);
         void* params[1] = {&a};
-        const hipError_t le = hipLaunchKernel(fns[slot], dim3((unsigned)grid), dim3(256), params, kTrainLdsBytes, st);
+        const hipError_t le = hipLaunchKernel(fns[slot], dim3((unsigned)grid), dim3(four ? 256 : 512), params, kTrainLdsBytes, st);
         if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_train_step launch");
     ReduceArgs r{};
     r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
