@@ -341,7 +341,7 @@ def trainer_loop_leg(args, device, tables):
     torch.cuda.empty_cache()
     return {"value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "ms_per_step": elapsed / max(steps, 1) * 1e3,
             "tables": tables, "episodes": episodes, "steps": steps,
-            "learner": "PokerQNetwork 40-128-128-64-32-13, fp32 MFMA kernels (act, train, reduce, AdamW), acting and training every step",
+            "learner": "PokerQNetwork 40-128-128-64-32-13, fp32 MFMA kernels (act + row lists, train, reduce + AdamW), acting and training every step",
             "counts_as": "n_games x steps incl. finished tables (trainGPU.py:108), episodes timed end to end incl. resets and the per-episode read-back",
             "reference_published": {"value": 2.5e7, "tables": 2000000, "hardware": "unnamed CUDA GPU",
                                     "source": "results/PokerGPU/runs/run_2.yaml:21,35 (BASELINE.md section 1)"}}

@@ -293,6 +293,11 @@ __device__ __forceinline__ void store_t(float* __restrict__ S, int unit0, const 
 // keep-mask bits of the 16 accumulator rows of tile `tile` (units 32*tile + rho(r) + 4h) for table `gid`:
 // unit u drops when the 16-bit uniform (call u / 8, word (u % 8) / 2, half u % 2) is below drop_p * 65536.
 __device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t gid, uint64_t step, int tile, int h, uint32_t thr) {
+    {   // keep the ten rounds' key schedule (uniform: 20 scalar registers per call site) from being hoisted out of the tile loop
+        uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        seed = ((uint64_t)hi << 32) | lo;
+    }
     // The two lanes of a column (h = 0, 1) need the same four calls, one half of each call's words: lane h makes calls
     // 2h and 2h + 1 and hands the partner its half of them through the lane pair.
     if (PULSE_QABL & 4) return 0xFFFFu;
