@@ -480,89 +480,6 @@ __device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const fl
     for (int j = 0; j < 8; ++j) dst[(k0 + j) * kLd + c] = v[j];
 }
 
-// the five bias vectors -> Bs (b1 @0, b2 @128, b3 @256, b4 @320, b5 @352; 384 floats), all threads of the workgroup
-__device__ __forceinline__ void stage_biases(float* __restrict__ Bs, const PulseQNet& n) {
-    const float* src[5] = {n.b1, n.b2, n.b3, n.b4, n.b5};
-    const int at[6] = {0, 128, 256, 320, 352, 384}, len[5] = {128, 128, 64, 32, n.n_actions};
-    for (int i = threadIdx.x; i < 384; i += blockDim.x) {
-        float v = 0.0f;
-#pragma unroll
-        for (int l = 0; l < 5; ++l) if (i >= at[l] && i < at[l] + len[l]) v = src[l][i - at[l]];
-        Bs[i] = v;
-    }
-}
-
-// The network (eval mode) on the 32 rows in Xs; layer 1's weights in w1r (loaded by the caller, before it gathered the
-// rows), biases in Bs.  Every layer issues the NEXT layer's weight loads behind its own MFMAs -- they land during its
-// epilogue -- and the barriers between the layers do not wait for them (lds_barrier): a layer never waits for L2.  Returns the Q tile in wavefront 0 (other
-// wavefronts: unspecified).  Ends on a barrier-free state: callers barrier before reusing LDS.
-template <int NK1>
-__device__ __forceinline__ f32x16 coop_forward_eval(const float (&w1r)[NK1][4], const PulseQNet& n, float* __restrict__ lds,
-                                                    const float* __restrict__ Bs, int wv, int c, int h) {
-    float* Xs = lds + CoopLds::Xs; float* A1 = lds + CoopLds::A1; float* A2 = lds + CoopLds::A2; float* A3 = lds + CoopLds::A3;
-    float* A4 = lds + CoopLds::A4; float* P = lds + CoopLds::P;
-    const int lane = c + 32 * h, A = n.n_actions;
-    const int ot = wv & 1, half = wv >> 1;
-    lds_barrier();                                                            // Xs complete
-    QSTAMP(2);
-    float w2r[16][4];
-    {   // layer 1: wavefront wv -> units [32wv, +32)
-        const f32x16 acc = mfma_w<NK1>(w1r, c, h, Xs, 0);
-        load_layer<true, 16>(w2r, n, 1, 32 * wv + c, h, 0, 128);
-        { float bz[16]; load_bias16(bz, Bs, 32 * wv, h); coop_epilogue<false>(acc, bz, 32 * wv, c, h, 0xFFFFu, 1.0f, A1, nullptr); }
-    }
-    lds_barrier();
-    QSTAMP(3);
-    float w3r[8][4];
-    {   // layer 2
-        const f32x16 acc = mfma_w<16>(w2r, c, h, A1, 0);
-        load_layer<true, 8>(w3r, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
-        { float bz[16]; load_bias16(bz, Bs + 128, 32 * wv, h); coop_epilogue<false>(acc, bz, 32 * wv, c, h, 0xFFFFu, 1.0f, A2, nullptr); }
-    }
-    lds_barrier();
-    QSTAMP(4);
-    float w4r[2][4];
-    load_layer<true, 2>(w4r, n, 3, c, h, 16 * wv, 16 * wv + 16);
-    {   // layer 3: 2 output tiles x 2 halves of k
-        f32x16 acc = mfma_w<8>(w3r, c, h, A2, 64 * half);
-        if (half == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) P[(ot * 16 + r) * 64 + lane] = acc[r];
-        }
-        lds_barrier();
-        if (half == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += P[(ot * 16 + r) * 64 + lane];
-            { float bz[16]; load_bias16(bz, Bs + 256, 32 * ot, h); coop_epilogue<false>(acc, bz, 32 * ot, c, h, 0xFFFFu, 1.0f, A3, nullptr); }
-        }
-    }
-    lds_barrier();
-    QSTAMP(5);
-    float w5r[4][4];
-    load_layer<true, 4>(w5r, n, 4, min(c, A - 1), h, 0, wv == 0 ? 32 : 0);
-    {   // layer 4: one output tile, k in quarters
-        f32x16 acc = mfma_w<2>(w4r, c, h, A3, 16 * wv);
-        if (wv > 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) P[((wv - 1) * 16 + r) * 64 + lane] = acc[r];
-        }
-        lds_barrier();
-        if (wv == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += (P[r * 64 + lane] + P[(16 + r) * 64 + lane]) + P[(32 + r) * 64 + lane];
-            { float bz[16]; load_bias16(bz, Bs + 320, 0, h); coop_epilogue<false>(acc, bz, 0, c, h, 0xFFFFu, 1.0f, A4, nullptr); }
-        }
-    }
-    lds_barrier();
-    QSTAMP(6);
-    f32x16 qv = zero16();
-    if (wv == 0) {
-        qv = mfma_w<4>(w5r, c, h, A4, 0);
-        bias_act<false>(qv, Bs + 352, 0, A, h);
-    }
-    return qv;
-}
-
 // Training: the target network on s' (eval) and the network on s (train mode) taken through the layers TOGETHER -- every
 // stage issues both networks' MFMAs and epilogues between one pair of barriers, so the two forwards cost 7 barrier
 // phases instead of 14.  The target's activations borrow the backward pass's delta buffers (free until then):
@@ -673,6 +590,98 @@ __device__ __forceinline__ void coop_forward_pair(const float (&w1t)[NK1][4], co
     }
 }
 
+template <bool TRAIN, int NR>
+__device__ __forceinline__ void coop_epilogue_n(const float (&v)[NR], const float (&bz)[NR], int unit0, int c, int h, uint32_t keep, float scale,
+                                                float* __restrict__ As, float* __restrict__ Gs) {
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) {                             // values r, r + 1 are units u, u + 1 (rho(i) = i below 4)
+        const int u = unit0 + rho(r) + 4 * h;
+        const f32x2 z = {v[r] + bz[r], v[r + 1] + bz[r + 1]};
+        const f32x2 m = {((keep >> r) & 1u) ? scale : 0.0f, ((keep >> (r + 1)) & 1u) ? scale : 0.0f};
+        f32x2 y, dy;
+        if (PULSE_QABL & 2) { y = z; dy = z; } else gelu_pair2(z, y, dy);
+        y = y * m;
+        As[u * kLd + c] = y.x; As[(u + 1) * kLd + c] = y.y;
+        if (TRAIN) { dy = dy * m; Gs[u * kLd + c] = dy.x; Gs[(u + 1) * kLd + c] = dy.y; }
+    }
+}
+
+// One network on the 32 rows in X, on the four wavefronts wq = 0..3 of a group; B1..B4 receive a_1..a_4 (G1..G4: g_1..g_4
+// when TRAIN), P is the group's 3072 floats of exchange space.  Returns the output tile in wavefront wq = 0.  7 barriers.
+template <bool TRAIN, int NK1, class Net>
+__device__ __forceinline__ f32x16 group_forward(const float (&w1r)[NK1][4], const Net& n, const float* __restrict__ X,
+                                                float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ B3, float* __restrict__ B4,
+                                                float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3, float* __restrict__ G4,
+                                                float* __restrict__ P, int wq, int c, int h, uint64_t seed, uint64_t gid, uint64_t step,
+                                                uint32_t thr, float scale) {
+    const int lane = c + 32 * h, ot = wq & 1, half = wq >> 1, A = n.n_actions;
+    lds_barrier();                                                            // X complete
+    float w2r[16][4];
+    {   // layer 1
+        float bz[16];
+        load_bias16(bz, net_b(n, 0), 32 * wq, h);
+        const f32x16 acc = mfma_w<NK1>(w1r, c, h, X, 0);
+        load_layer<true, 16>(w2r, n, 1, 32 * wq + c, h, 0, 128);
+        coop_epilogue<TRAIN>(acc, bz, 32 * wq, c, h, 0xFFFFu, 1.0f, B1, G1);
+    }
+    lds_barrier();
+    float w3r[8][4];
+    {   // layer 2 (+ Dropout when TRAIN, Player.py:194)
+        float bz[16];
+        load_bias16(bz, net_b(n, 1), 32 * wq, h);
+        const f32x16 acc = mfma_w<16>(w2r, c, h, B1, 0);
+        load_layer<true, 8>(w3r, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
+        coop_epilogue<TRAIN>(acc, bz, 32 * wq, c, h, TRAIN ? dropout_keep_bits(seed, gid, step, wq, h, thr) : 0xFFFFu, TRAIN ? scale : 1.0f, B2, G2);
+    }
+    lds_barrier();
+    float w4r[2][4];
+    {   // layer 3: 2 output tiles x 2 halves of k; the two wavefronts of a tile finish 8 accumulator registers each (+ Dropout, :197)
+        float bz8[8], own[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bz8[i] = net_b(n, 2)[32 * ot + 16 * half + rho(i) + 4 * h];
+        const f32x16 acc = mfma_w<8>(w3r, c, h, B2, 64 * half);
+        load_layer<true, 2>(w4r, n, 3, c, h, 16 * wq, 16 * wq + 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) P[((ot * 2 + (1 - half)) * 8 + i) * 64 + lane] = half ? acc[i] : acc[8 + i];     // the partner's registers
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) own[i] = (half ? acc[8 + i] : acc[i]) + P[((ot * 2 + half) * 8 + i) * 64 + lane];
+        const uint32_t keep = TRAIN ? (dropout_keep_bits(seed, gid, step, 4 + ot, h, thr) >> (8 * half)) : 0xFFFFu;
+        coop_epilogue_n<TRAIN, 8>(own, bz8, 32 * ot + 16 * half, c, h, keep, TRAIN ? scale : 1.0f, B3, G3);
+    }
+    lds_barrier();
+    float w5r[4][4];
+    {   // layer 4: one output tile, k in quarters; wavefront wq finishes registers 4 wq .. 4 wq + 3 (units 8 wq + i + 4h)
+        float bz4[4], own[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bz4[i] = net_b(n, 3)[8 * wq + i + 4 * h];
+        const f32x16 acc = mfma_w<2>(w4r, c, h, B3, 16 * wq);
+        load_layer<true, 4>(w5r, n, 4, min(c, A - 1), h, 0, wq == 0 ? 32 : 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g != wq) {
+                const int slot = (wq - g - 1) & 3;                // 0..2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) P[((g * 3 + slot) * 4 + i) * 64 + lane] = acc[4 * g + i];
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float mine = wq == 0 ? acc[i] : wq == 1 ? acc[4 + i] : wq == 2 ? acc[8 + i] : acc[12 + i];
+            own[i] = mine + ((P[((wq * 3 + 0) * 4 + i) * 64 + lane] + P[((wq * 3 + 1) * 4 + i) * 64 + lane]) + P[((wq * 3 + 2) * 4 + i) * 64 + lane]);
+        }
+        coop_epilogue_n<TRAIN, 4>(own, bz4, 8 * wq, c, h, 0xFFFFu, 1.0f, B4, G4);
+    }
+    lds_barrier();
+    f32x16 qv = zero16();
+    if (wq == 0) {
+        qv = mfma_w<4>(w5r, c, h, B4, 0);
+        bias_act<false>(qv, net_b(n, 4), 0, A, h);
+    }
+    return qv;
+}
+
 // 256 candidate rows -> ids of the selected ones in List[0..count), count returned to every thread
 __device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, int row) {
     int* list = reinterpret_cast<int*>(lds + CoopLds::List);
@@ -706,8 +715,6 @@ __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
     const int K1 = a.net.state_dim, K1r = (K1 + 7) & ~7;
     float w1r[NK1][4];
     load_layer<VEC, NK1>(w1r, a.net, 0, 32 * wv + c, h, 0, K1r);           // in flight during the compaction
-    float* Bs = lds + CoopLds::P + 3 * 16 * 64;                             // the second network's half of P: free in this kernel
-    stage_biases(Bs, a.net);
     // The rows the NEXT training launch will use (row_mask_out & seat status ACTIVE / ALLIN, Player.py:258-261) are known
     // here already -- it trains on this observation: their lists are written now and the select launch is not needed.
     int* tcount = reinterpret_cast<int*>(lds + CoopLds::List) + 260;
@@ -733,7 +740,8 @@ __global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
         const int rowc = t0 + c < count ? list[t0 + c] : -1;
         lds_barrier();                                                        // previous tile's readers are done
         coop_load_rows<VEC>(lds + CoopLds::Xs, a.states, a.row_stride, K1, rowc, wv, c, h);
-        const f32x16 qv = coop_forward_eval<NK1>(w1r, a.net, lds, Bs, wv, c, h);
+        const f32x16 qv = group_forward<false, NK1>(w1r, a.net, lds + CoopLds::Xs, lds + CoopLds::A1, lds + CoopLds::A2, lds + CoopLds::A3, lds + CoopLds::A4,
+                                                    nullptr, nullptr, nullptr, nullptr, lds + CoopLds::P, wv, c, h, 0, 0, 0, 0, 1.0f);
         if (wv == 0) {
             const bool live = rowc >= 0;
             if (a.q_out && live) {
@@ -981,8 +989,9 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
         __syncthreads();
     }
     const int G = (int)gridDim.x;
-    const int r_tile = min(32, max(8, (T + G - 1) / G));
-    const int n_tiles = (T + r_tile - 1) / r_tile;
+    // full tiles: fewer slices to reduce than with T rows spread over all the workgroups (a tile costs the same with 25 rows
+    // as with 32), and every workgroup at most one more tile than any other
+    const int n_tiles = (T + 31) / 32;
     for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
         {
             const bool first = !used;
@@ -1088,9 +1097,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     }
 
     QSTAMP(8);
-    if (!used) {                                                  // no tile for this workgroup: a zero slice
-        for (int i = threadIdx.x; i < kSliceStats; i += 256) part[i] = 0.0f;
-    } else if (K1 <= 32) {                                        // the second column tile of layer 1 was never touched
+    if (used && K1 <= 32) {                                       // (no tile for this workgroup: the reduce launch skips its slice)                                        // the second column tile of layer 1 was never touched
         for (int i = threadIdx.x; i < 4 * 1024; i += 256) part[(size_t)(kSliceBlk1 + 2 * (i >> 10) + 1) * 1024 + (i & 1023)] = 0.0f;
     }
     // db rows: every bias is written by exactly one wavefront
@@ -1119,98 +1126,6 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
 // four do, the epilogues of layers 3 and 4 split between them); the backward phases deal their 16 + 4 products per layer to
 // all eight (delta tiles on 0-3, the weight-gradient blocks on 4-7, equal MFMA counts).  Same tiles, same LDS image, same
 // slice layout; a block of the slice is still owned by one wavefront for the whole launch.
-template <bool TRAIN, int NR>
-__device__ __forceinline__ void coop_epilogue_n(const float (&v)[NR], const float (&bz)[NR], int unit0, int c, int h, uint32_t keep, float scale,
-                                                float* __restrict__ As, float* __restrict__ Gs) {
-#pragma unroll
-    for (int r = 0; r < NR; r += 2) {                             // values r, r + 1 are units u, u + 1 (rho(i) = i below 4)
-        const int u = unit0 + rho(r) + 4 * h;
-        const f32x2 z = {v[r] + bz[r], v[r + 1] + bz[r + 1]};
-        const f32x2 m = {((keep >> r) & 1u) ? scale : 0.0f, ((keep >> (r + 1)) & 1u) ? scale : 0.0f};
-        f32x2 y, dy;
-        if (PULSE_QABL & 2) { y = z; dy = z; } else gelu_pair2(z, y, dy);
-        y = y * m;
-        As[u * kLd + c] = y.x; As[(u + 1) * kLd + c] = y.y;
-        if (TRAIN) { dy = dy * m; Gs[u * kLd + c] = dy.x; Gs[(u + 1) * kLd + c] = dy.y; }
-    }
-}
-
-// One network on the 32 rows in X, on the four wavefronts wq = 0..3 of a group; B1..B4 receive a_1..a_4 (G1..G4: g_1..g_4
-// when TRAIN), P is the group's 3072 floats of exchange space.  Returns the output tile in wavefront wq = 0.  7 barriers.
-template <bool TRAIN, int NK1>
-__device__ __forceinline__ f32x16 group_forward(const float (&w1r)[NK1][4], const FlatNet& n, const float* __restrict__ X,
-                                                float* __restrict__ B1, float* __restrict__ B2, float* __restrict__ B3, float* __restrict__ B4,
-                                                float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3, float* __restrict__ G4,
-                                                float* __restrict__ P, int wq, int c, int h, uint64_t seed, uint64_t gid, uint64_t step,
-                                                uint32_t thr, float scale) {
-    const int lane = c + 32 * h, ot = wq & 1, half = wq >> 1, A = n.n_actions;
-    lds_barrier();                                                            // X complete
-    float w2r[16][4];
-    {   // layer 1
-        float bz[16];
-        load_bias16(bz, net_b(n, 0), 32 * wq, h);
-        const f32x16 acc = mfma_w<NK1>(w1r, c, h, X, 0);
-        load_layer<true, 16>(w2r, n, 1, 32 * wq + c, h, 0, 128);
-        coop_epilogue<TRAIN>(acc, bz, 32 * wq, c, h, 0xFFFFu, 1.0f, B1, G1);
-    }
-    lds_barrier();
-    float w3r[8][4];
-    {   // layer 2 (+ Dropout when TRAIN, Player.py:194)
-        float bz[16];
-        load_bias16(bz, net_b(n, 1), 32 * wq, h);
-        const f32x16 acc = mfma_w<16>(w2r, c, h, B1, 0);
-        load_layer<true, 8>(w3r, n, 2, 32 * ot + c, h, 64 * half, 64 * half + 64);
-        coop_epilogue<TRAIN>(acc, bz, 32 * wq, c, h, TRAIN ? dropout_keep_bits(seed, gid, step, wq, h, thr) : 0xFFFFu, TRAIN ? scale : 1.0f, B2, G2);
-    }
-    lds_barrier();
-    float w4r[2][4];
-    {   // layer 3: 2 output tiles x 2 halves of k; the two wavefronts of a tile finish 8 accumulator registers each (+ Dropout, :197)
-        float bz8[8], own[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bz8[i] = net_b(n, 2)[32 * ot + 16 * half + rho(i) + 4 * h];
-        const f32x16 acc = mfma_w<8>(w3r, c, h, B2, 64 * half);
-        load_layer<true, 2>(w4r, n, 3, c, h, 16 * wq, 16 * wq + 16);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) P[((ot * 2 + (1 - half)) * 8 + i) * 64 + lane] = half ? acc[i] : acc[8 + i];     // the partner's registers
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) own[i] = (half ? acc[8 + i] : acc[i]) + P[((ot * 2 + half) * 8 + i) * 64 + lane];
-        const uint32_t keep = TRAIN ? (dropout_keep_bits(seed, gid, step, 4 + ot, h, thr) >> (8 * half)) : 0xFFFFu;
-        coop_epilogue_n<TRAIN, 8>(own, bz8, 32 * ot + 16 * half, c, h, keep, TRAIN ? scale : 1.0f, B3, G3);
-    }
-    lds_barrier();
-    float w5r[4][4];
-    {   // layer 4: one output tile, k in quarters; wavefront wq finishes registers 4 wq .. 4 wq + 3 (units 8 wq + i + 4h)
-        float bz4[4], own[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bz4[i] = net_b(n, 3)[8 * wq + i + 4 * h];
-        const f32x16 acc = mfma_w<2>(w4r, c, h, B3, 16 * wq);
-        load_layer<true, 4>(w5r, n, 4, min(c, A - 1), h, 0, wq == 0 ? 32 : 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g != wq) {
-                const int slot = (wq - g - 1) & 3;                // 0..2
-#pragma unroll
-                for (int i = 0; i < 4; ++i) P[((g * 3 + slot) * 4 + i) * 64 + lane] = acc[4 * g + i];
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float mine = wq == 0 ? acc[i] : wq == 1 ? acc[4 + i] : wq == 2 ? acc[8 + i] : acc[12 + i];
-            own[i] = mine + ((P[((wq * 3 + 0) * 4 + i) * 64 + lane] + P[((wq * 3 + 1) * 4 + i) * 64 + lane]) + P[((wq * 3 + 2) * 4 + i) * 64 + lane]);
-        }
-        coop_epilogue_n<TRAIN, 4>(own, bz4, 8 * wq, c, h, 0xFFFFu, 1.0f, B4, G4);
-    }
-    lds_barrier();
-    f32x16 qv = zero16();
-    if (wq == 0) {
-        qv = mfma_w<4>(w5r, c, h, B4, 0);
-        bias_act<false>(qv, net_b(n, 4), 0, A, h);
-    }
-    return qv;
-}
-
 template <bool VEC, int NK1>
 __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
     extern __shared__ float lds[];
@@ -1264,8 +1179,9 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
         __syncthreads();
     }
     const int G = (int)gridDim.x;
-    const int r_tile = min(32, max(8, (T + G - 1) / G));
-    const int n_tiles = (T + r_tile - 1) / r_tile;
+    // full tiles: fewer slices to reduce than with T rows spread over all the workgroups (a tile costs the same with 25 rows
+    // as with 32), and every workgroup at most one more tile than any other
+    const int n_tiles = (T + 31) / 32;
     for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
         const bool first = !used;
         used = true;
@@ -1368,9 +1284,7 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
     }
 
     QSTAMP(8);
-    if (!used) {
-        for (int i = threadIdx.x; i < kSliceStats; i += 512) part[i] = 0.0f;
-    } else if (K1 <= 32) {                                        // the second column tile of layer 1 was never touched
+    if (used && K1 <= 32) {                                       // the second column tile of layer 1 was never touched
         for (int i = threadIdx.x; i < 4 * 1024; i += 512) part[(size_t)(kSliceBlk1 + 2 * (i >> 10) + 1) * 1024 + (i & 1023)] = 0.0f;
     }
     if (used && h0 == 0) {                                        // db rows: every bias is written by exactly one wavefront
@@ -1445,16 +1359,25 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (j0 < kSliceStats) {
         const float* p = a.partials + j0;
+        const float* flag = a.partials + kSliceStats + 3;            // 1: the slice's workgroup had a tile (else its blocks are stale)
         int b = (int)((long long)a.n_blocks * grp / 8);
         const int end = (int)((long long)a.n_blocks * (grp + 1) / 8);
         for (; b + 8 <= end; b += 8) {
-            float4 v[8];
+            float4 v[8]; float u[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(b + u) * pitch);
+            for (int i = 0; i < 8; ++i) u[i] = flag[(size_t)(b + i) * pitch];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            for (int i = 0; i < 8; ++i) {
+                v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (u[i] != 0.0f) v[i] = *reinterpret_cast<const float4*>(p + (size_t)(b + i) * pitch);   // (the two halves of a wavefront are on different slices)
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
         }
-        for (; b < end; ++b) { const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * pitch); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        for (; b < end; ++b) {
+            if (flag[(size_t)b * pitch] == 0.0f) continue;
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * pitch); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
     part8[grp][lane] = acc;
     __syncthreads();
@@ -1737,8 +1660,8 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
             if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
             attr_set[slot] = fns[slot];
         }
-        // persistent workgroups (157 KB of LDS: one per CU); a tile holds at least 8 selected rows
-        const int grid = std::min((n_rows + 7) / 8, (int)t->max_blocks);
+        // persistent workgroups (157 KB of LDS: one per CU), one per possible tile of 32 rows at most
+        const int grid = std::min((n_rows + 31) / 32, (int)t->max_blocks);
         void* params[1] = {&a};
         const hipError_t le = hipLaunchKernel(fns[slot], dim3((unsigned)grid), dim3(four ? 256 : 512), params, kTrainLdsBytes, st);
         if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_train_step launch");
