@@ -394,7 +394,7 @@ int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row
                           int32_t* select_scratch, int64_t select_words, void* stream);
 
 /* PokerQNetwork.train_step (Player.py:255-294) as up to three launches: (0) the row filter as lists of row ids per
- * window (skipped when pulse_qnet_act_select wrote them); (1) the listed rows dealt evenly to the workgroups: TD target +
+ * window (skipped when pulse_qnet_act_select wrote them); (1) the listed rows in tiles of 32, dealt to the workgroups: TD target +
  * forward (train mode) + backward on the matrix cores, gradient sums accumulated per workgroup; (2) reduction of the
  * workgroups' slices, then -- in the same launch -- gradient mean / clip_grad_norm_ / AdamW / target sync.
  * The network and its target each live in ONE flat fp32 buffer of pulse_qnet_param_count() floats laid out
