@@ -38,6 +38,17 @@ def test_error_reporting_and_validation_without_gpu():
     assert b"unsupported shape" in lib.pulse_last_error()
     with pytest.raises(ValueError):
         _native.check(-1, "probe")
+    # the learner's entry points check their scratch before anything is launched
+    net = _native.QNet()
+    net.state_dim, net.n_actions = 40, 13
+    dummy = (C.c_int32 * 8)()
+    ptr = C.addressof(dummy)
+    assert lib.pulse_qnet_act_select(C.byref(net), ptr, 40, 1024, ptr, 0, 0.1, 1, 1, 0, ptr, None, ptr, None, 0, None) == -1
+    assert b"pulse_qnet_act_select: needs" in lib.pulse_last_error()
+    assert lib.pulse_qnet_act_select(C.byref(net), ptr, 40, 1024, ptr, 0, 0.1, 1, 1, 0, ptr, None, ptr, ptr, 100, None) == -1
+    assert b"259 words per 256 rows" in lib.pulse_last_error()
+    net.state_dim = 100                                    # the cooperative tile takes up to 64 inputs
+    assert lib.pulse_qnet_act_select(C.byref(net), ptr, 100, 1024, ptr, 0, 0.1, 1, 1, 0, ptr, None, ptr, ptr, 1 << 20, None) == -1
 
 
 def test_product_classes_refuse_cpu_devices():
