@@ -30,8 +30,8 @@ acts = torch.zeros(N, dtype=torch.long, device=dev)
 mask = torch.zeros(N, dtype=torch.uint8, device=dev)
 n_blocks = (N + 127) // 128
 buf = torch.zeros((n_blocks, 16), dtype=torch.int64, device=dev)
-names = ["weight loads issued + compaction", "row gather -> first barrier", "layer 1", "layer 2", "layer 3", "layer 4", "layer 5 + argmax + store",
-         "exit"]
+names = ["weight loads issued + compaction (incl. the training row lists)", "row gather + the five layers + argmax + store", "exit"]
+COLS = [0, 1, 7, 8]                     # the stamps the kernel takes (csrc/qnet.hip: qnet_act4_kernel)
 
 
 net = q._net_struct(q.network)
@@ -39,7 +39,7 @@ for rep in range(3):
     _native.check(lib.pulse_qnet_act(C.byref(net), s.data_ptr(), 40, N, seat.data_ptr(), 1, C.c_float(0.1), 1, rep, 0, acts.data_ptr(), None, None,
                                      mask.data_ptr(), torch.cuda.current_stream().cuda_stream), "act")
 torch.cuda.synchronize()
-acc = np.zeros(8)
+acc = np.zeros(3)
 for rep in range(5):
     buf.zero_()
     lib.pulse_debug_set_qnet_stamp_buffer(buf.data_ptr())
@@ -48,7 +48,7 @@ for rep in range(5):
     torch.cuda.synchronize()
     st = buf.cpu().numpy().astype(np.int64)
     st = st[st[:, 8] > 0]
-    acc += np.diff(st[:, :9], axis=1).mean(axis=0)
+    acc += np.diff(st[:, COLS], axis=1).mean(axis=0)
     span = st[:, 8].max() - st[:, 0].min()
     starts = st[:, 0] - st[:, 0].min()
 lib.pulse_debug_set_qnet_stamp_buffer(None)
@@ -56,4 +56,4 @@ acc /= 5
 print(f"N={N} learner fraction {frac:.3f}: kernel span {span} ticks over {len(st)} workgroups; per workgroup total {acc.sum():.0f}")
 print(f"   workgroup start offsets: median {np.median(starts):.0f}, 90 % {np.percentile(starts, 90):.0f}, max {starts.max()}")
 for n, c in zip(names, acc):
-    print(f"   {n:34s} {c:9.0f}  {100 * c / acc.sum():5.1f} %")
+    print(f"   {n:66s} {c:9.0f}  {100 * c / acc.sum():5.1f} %")
