@@ -1,4 +1,4 @@
-"""Where the training kernel (csrc/qnet.hip: qnet_train_kernel) spends its time: runs the diagnostic build
+"""Where the training kernel (csrc/qnet.hip: qnet_train8_kernel, or qnet_train_kernel with PULSE_TRAIN_WAVES=4) spends its time: runs the diagnostic build
 (libpulse_hip_stamps.so, `make -C pulselib_amd/csrc stamps`), whose kernel stores the clock at the phase boundaries
 of each workgroup's tile, and prints mean ticks per segment.  Read the SHARES."""
 import ctypes as C
@@ -50,6 +50,7 @@ for rep in range(5):
 lib.pulse_debug_set_qnet_stamp_buffer(None)
 acc /= 5
 print(f"N={N} mask fraction {frac}: kernel span {span} ticks; per workgroup (first... last tile overwrite): total {acc.sum():.0f}")
-print(f"   layer 2 bwd split: dW blocks {extra[0]:.0f}, delta_1 tile {extra[1]:.0f}, wait at barrier {extra[2]:.0f}")
+if (st[:, 10] > 0).all():          # the four-wavefront kernel (PULSE_TRAIN_WAVES=4) stamps inside the layer-2 phase
+    print(f"   layer 2 bwd split: dW blocks {extra[0]:.0f}, delta_1 tile {extra[1]:.0f}, wait at barrier {extra[2]:.0f}")
 for n, c in zip(names, acc):
     print(f"   {n:22s} {c:9.0f}  {100 * c / acc.sum():5.1f} %")
