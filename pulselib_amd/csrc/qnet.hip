@@ -284,12 +284,6 @@ __device__ __forceinline__ void gelu_pair2(f32x2 x, f32x2& y, f32x2& dy) {
     dy = fma2(x * splat2(0.39894228040143267794f), e, cdf);
 }
 
-// store an accumulator tile as [unit0 + row-of-tile][column]
-__device__ __forceinline__ void store_t(float* __restrict__ S, int unit0, const f32x16& v, int c, int h) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[(unit0 + rho(r) + 4 * h) * kLd + c] = v[r];
-}
-
 // keep-mask bits of the 16 accumulator rows of tile `tile` (units 32*tile + rho(r) + 4h) for table `gid`:
 // unit u drops when the 16-bit uniform (call u / 8, word (u % 8) / 2, half u % 2) is below drop_p * 65536.
 __device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t gid, uint64_t step, int tile, int h, uint32_t thr) {
@@ -323,9 +317,10 @@ __device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t gi
     return bits;
 }
 
-// acc[out, row] = sum over the NK8 steps of 8 k from k0 (k < k1) of W[out_row][k] * S[k][row].  All the weight loads
-// of the call are issued before the first MFMA (the loop is otherwise one L2 round trip per four MFMAs).  VEC: W rows are
-// 16-byte aligned and K % 8 == 0 (a float4 feeds four MFMAs); else scalar loads guarded by k < K.
+// A layer's product acc[out, row] = sum over NK8 steps of 8 k from k0 of W[out_row][k] * S[k][row] in two halves: the weight loads
+// (load_w) and the MFMAs on them (mfma_w), so that a caller can issue the loads a layer ahead (all of a call's loads go out
+// together: a loop over k is otherwise one L2 round trip per four MFMAs).  VEC: W rows are 16-byte aligned and K % 8 == 0
+// (a float4 feeds four MFMAs); else scalar loads guarded by k < K.
 template <bool VEC, int NK8>
 __device__ __forceinline__ void load_w(float (&wa)[NK8][4], const float* __restrict__ w, int K, int out_row, int h, int k0, int k1) {
     const float* wr = w + (size_t)out_row * K;
@@ -378,14 +373,6 @@ __device__ __forceinline__ f32x16 mfma_w(const float (&wa)[NK8][4], int c, int h
     }
     return acc;
 }
-template <bool VEC, int NK8>
-__device__ __forceinline__ f32x16 dense_lds(const float* __restrict__ w, int K, int out_row, int c, int h, const float* __restrict__ S,
-                                            int k0, int k1) {
-    float wa[NK8][4];
-    load_w<VEC, NK8>(wa, w, K, out_row, h, k0, k1);
-    return mfma_w<NK8>(wa, c, h, S, k0);
-}
-
 // Workgroup barrier for waves that talk through LDS only: waits for this wave's LDS traffic, not for its global loads
 // (__syncthreads' release fence is s_waitcnt vmcnt(0) too, which puts every weight load issued ahead of a barrier back on
 // the critical path).
