@@ -487,3 +487,28 @@ def test_row_lists_from_the_act_launch_equal_the_selection_launch(g, n):
     other = dev["states"].clone()
     q.train_step_native(other, acts, dev["rewards"], dev["next_states"], dev["dones"], mask, step_counter=9)
     assert q._struct_cache["train"].select_from_act == 0
+
+
+def test_four_and_eight_wavefront_training_kernels_agree(g, tmp_path):
+    """PULSE_TRAIN_WAVES=4 keeps the four-wavefront training kernel (comparison runs): the same tiles and dropout draws, layer 4's
+    k quarters summed in another order -- parameters after three steps agree to a few ulp of a learning-rate step."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_qnetwork_gpu import _qnet, _batch, _flat, DEV\n"
+        "g = np.load(%r)\n"
+        "q = _qnet(g, 's40', seed=21); b = _batch(9000, 31)\n"
+        "dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}\n"
+        "for s in range(3): rep = q.train_step_native(dev['states'], dev['actions'], dev['rewards'], dev['next_states'], dev['dones'], dev['row_mask'], step_counter=s)\n"
+        "np.save(sys.argv[1], np.concatenate([_flat(q.network), rep.cpu().numpy()]))\n") % (str(root), str(root / "tests" / "golden" / "qnetwork.npz"))
+    out = {}
+    for waves in ("4", "8"):
+        path = tmp_path / f"p{waves}.npy"
+        env = dict(__import__("os").environ, PULSE_TRAIN_WAVES=waves)
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, cwd=str(root), timeout=300)
+        out[waves] = np.load(path)
+    assert out["4"][-4] == out["8"][-4] > 0                                  # rows trained on
+    np.testing.assert_allclose(out["4"][:-4], out["8"][:-4], rtol=0, atol=2e-7)     # lr = 2e-4: a step moves a weight by <= 2e-4
