@@ -7,7 +7,7 @@ What is native here:
     MFMA kernel (csrc/qnet.hip) reading the module's own weight tensors; no mask gather / scatter, no
     host sync, draws keyed by (seed, global table id, step) like the scripted opponents';
   * `train_step_native`: the whole update -- row filter, forward in train mode, TD target, backward, gradient
-    clipping, AdamW, target sync -- as three launches of csrc/qnet.hip with no host sync (the reference's boolean
+    clipping, AdamW, target sync -- as two launches of csrc/qnet.hip (three without act_into's row lists) with no host sync (the reference's boolean
     indexing costs a device->host sync per mask);
   * `train_step_masked`: the same sync-free contract on PyTorch-ROCm autograd (every row goes through with a 0/1
     weight), kept as the torch cross-check of the native path.
@@ -227,7 +227,7 @@ class PokerQNetwork(nn.Module):
 
     def train_step_native(self, states, actions, rewards, next_states, dones, row_mask=None, step_counter=None, terminated=None,
                           reward_sum=None):
-        """train_step (Player.py:255-294) as three launches on the env's stream and no host sync: row filter
+        """train_step (Player.py:255-294) as two or three launches on the env's stream and no host sync: row filter
         (row_mask & seat status ACTIVE/ALLIN) + TD target + forward + backward on the matrix cores -> reduction of the
         workgroups' gradient slices -> gradient mean, clip_grad_norm_, AdamW, target sync every update_freq optimizer
         steps.  `terminated` (bool[n], |= dones) and `reward_sum` (float64 scalar, += rewards over row_mask) fold the
