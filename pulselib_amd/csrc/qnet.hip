@@ -1349,6 +1349,18 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
         const float* flag = a.partials + kSliceStats + 3;            // 1: the slice's workgroup had a tile (else its blocks are stale)
         int b = (int)((long long)a.n_blocks * grp / 8);
         const int end = (int)((long long)a.n_blocks * (grp + 1) / 8);
+        for (; b + 16 <= end; b += 16) {
+            float4 v[16]; float u[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) u[i] = flag[(size_t)(b + i) * pitch];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (u[i] != 0.0f) v[i] = *reinterpret_cast<const float4*>(p + (size_t)(b + i) * pitch);   // (the two halves of a wavefront are on different slices)
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+        }
         for (; b + 8 <= end; b += 8) {
             float4 v[8]; float u[8];
 #pragma unroll
