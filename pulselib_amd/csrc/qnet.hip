@@ -236,8 +236,9 @@ constexpr int kLd = 33;
 struct CoopLds {                 // offsets in floats into the dynamic LDS block
     static constexpr int Xs = 0, A1 = Xs + 64 * kLd, A2 = A1 + 128 * kLd, A3 = A2 + 128 * kLd, A4 = A3 + 64 * kLd,
                          P = A4 + 32 * kLd,                    // 2 x (3 x 16 x 64) partial sums (two networks in flight in training)
-                         List = P + 2 * 3 * 16 * 64,           // 256 row ids + 8 counters
-                         Tgt = List + 264,                     // 32 TD targets
+                         List = P + 2 * 3 * 16 * 64,           // act: row ids of the window + wavefront counts; training: first positions of
+                                                               // the threads' windows (256) + counts
+                         Tgt = List + 264,                     // 32 words: max_a' Q_target per column, wavefront sums at the end
                          EndEval = Tgt + 32,
                          G1 = EndEval, G2 = G1 + 128 * kLd, G3 = G2 + 128 * kLd, G4 = G3 + 64 * kLd,
                          Da = G4 + 32 * kLd, Db = Da + 128 * kLd, EndTrain = Db + 128 * kLd;
