@@ -403,7 +403,8 @@ int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row
  * pulse_qnet_slice_floats()] scratch (max_blocks = number of persistent workgroups, 256 = one per CU; a workgroup's
  * slice is laid out for its own stores, not in parameter order).  step: device int64 optimizer step count
  * (bias correction, target sync every update_freq steps).  stats: device fp32[4] scratch.  report: device fp32[4] out:
- * [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping.
+ * [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping, [3] 0 (-1: the reduce launch's workgroups did not
+ * all arrive at their meeting within 5 s and no update was applied -- never observed).
  * Row filter: row_mask[r] != 0 (NULL: all) and states[r][12] in {0, 2} (:261); if no row passes, nothing changes (:262).
  * Trainer bookkeeping folded in (both optional, scripts/Poker/trainGPU.py:86,96): terminated (device uint8[n_rows],
  * NULL = skip) gets terminated[r] |= dones[r]; reward_sum (device double, NULL = skip) += sum of rewards over the

@@ -1432,9 +1432,11 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     if (FUSED) {
         if (threadIdx.x < 64) {                                   // wavefront 0: lanes 0..7 watch one counter each
             const unsigned want = (gridDim.x + 7 - (threadIdx.x & 7)) / 8;      // workgroups b with b % 8 == lane
-            for (;;) {
+            bool met = true;
+            for (const long long t0 = wall_clock64();;) {
                 const unsigned got = threadIdx.x < 8 ? __hip_atomic_load(a.meet + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
                 if (__ballot(got < want) == 0ull) break;
+                if (wall_clock64() - t0 > 500000000ll) { met = false; break; }   // 5 s of the 100 MHz clock: never seen; no update then
                 __builtin_amdgcn_s_sleep(2);
             }
             float tot = 0.0f;                                      // the same order in every workgroup: the update does not depend on timing
@@ -1442,7 +1444,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
                 tot += __hip_atomic_load(reinterpret_cast<float*>(a.meet + 8 + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
-            if (threadIdx.x == 0) { bc[0] = tot; bc[1] = rows; }
+            if (threadIdx.x == 0) { bc[0] = tot; bc[1] = met ? rows : 0.0f; if (!met) w.report[3] = -1.0f; }
         }
         __syncthreads();
         const float total_ss = bc[0], count = bc[1];
