@@ -86,7 +86,7 @@ def parse_args(argv=None):
                     help="how the ranks exchange the stop rule's counts (auto: shared memory with the nccl backend, torch.distributed with gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
-    ap.add_argument("--trainer-loop", choices=["auto", "on", "off"], default="auto", help="auto: at N = 1")
+    ap.add_argument("--trainer-loop", choices=["auto", "on", "off"], default="auto", help="auto = on (N > 1: data-parallel learner, the per-GPU size only)")
     ap.add_argument("--trainer-episodes", type=int, default=12)
     ap.add_argument("--trainer-tables-large", type=int, default=2000000, help="second trainer-loop size (the reference's published N_GAMES); 0 = skip")
     ap.add_argument("--other-envs", choices=["auto", "on", "off"], default="auto", help="2048 / Q-learning / Particle2D / Blackjack records; auto: at N = 1")
@@ -207,9 +207,15 @@ class EpisodeLoop:
         return done
 
 
+REPORT_EVERY = 10      # scripts/Poker/trainGPU.py:110: the reference reports every 10th episode
+
+
 class EpisodeStatsReducer:
-    """The only cross-GPU exchange of the data path besides the stop rule's count: per-episode statistics
-    (RCCL all-reduce over xGMI of two doubles, asynchronous).  Accumulates {sum of the last step's rewards, tables done}."""
+    """The only cross-GPU exchange of the data path besides the stop rule's count: the episode statistics {sum of the last
+    step's rewards, tables done}.  Every rank accumulates its own CUMULATIVE totals on the device (inside the reset launch);
+    they are all-reduced (RCCL over xGMI, asynchronous) at the reference's reporting cadence -- every REPORT_EVERY-th
+    episode -- and once at the end, not at every episode: at 65,536 tables an episode is ~270 us, and an all-reduce per
+    episode would be ~3,700 collectives per second and rank, each with two cross-stream dependencies, for totals nobody reads."""
 
     def __init__(self, env, device, world):
         import torch
@@ -235,25 +241,35 @@ class EpisodeStatsReducer:
     def after_reset(self, loop):
         """... and AFTER the reset was enqueued: the all-reduce (its enqueue costs the host tens of microseconds, which
         the GPU spends resetting instead of waiting for the next episode's first launch)."""
-        if self.world == 1:
+        if self.world == 1 or loop.episode % REPORT_EVERY != 0:      # (loop.episode: episodes ended so far -- the same on every rank)
             return
+        self._reduce(asynchronous=True)
+
+    def _reduce(self, asynchronous):
         import torch.distributed as dist
-        if dist.get_backend() != "gloo":
-            self.reduced.copy_(self.local)           # (after the reset launch that completed the sums, in stream order)
         if dist.get_backend() == "gloo":             # one-GPU rehearsal: gloo reduces host copies
             host = self.local.cpu()
             dist.all_reduce(host)
             self.reduced.copy_(host)
         else:
-            self.work = dist.all_reduce(self.reduced, async_op=True)
+            self.reduced.copy_(self.local)           # (after the reset launch that completed the sums, in stream order)
+            work = dist.all_reduce(self.reduced, async_op=True)
+            if asynchronous:
+                self.work = work
+            else:
+                work.wait()
         self.collectives += 1
 
     def totals(self):
+        """Job-wide totals up to the last episode boundary (called by every rank at the same point of its loop)."""
         if self.work is not None:
             self.work.wait()
             self.work = None
+        if self.world > 1:
+            self._reduce(asynchronous=False)         # the episodes since the last report
         t = self.env.episode_stats_totals(self.reduced if self.world > 1 else self.local).cpu().tolist()
-        return {"last_step_reward_sum": t[0], "tables_done_at_episode_end": t[1], "episode_collectives": self.collectives}
+        return {"last_step_reward_sum": t[0], "tables_done_at_episode_end": t[1], "episode_collectives": self.collectives,
+                "reduced_every_episodes": REPORT_EVERY}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (child)
@@ -314,34 +330,55 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------------------ trainer loop leg
-def trainer_loop_leg(args, device, tables):
+def trainer_loop_leg(args, device, tables, rank=0, world=1, dist=None):
     """The second line of SURVEY.md 8d: the reference trainer's loop (scripts/Poker/trainGPU.py:57-108) -- the learner
-    acting and training every step -- on the native path (scripts/trainGPU.py: train_agent_fused)."""
+    acting and training every step -- on the native path (scripts/trainGPU.py: train_agent_fused).
+    N > 1 (one process per GPU): `tables` tables per rank with the job's global table ids, the learner data-parallel --
+    pulse_qnet_train_grads on the rank's rows, ONE all-reduce of the 130 KB gradient sum + row count (RCCL over xGMI),
+    pulse_qnet_train_apply: the identical AdamW step on every rank -- the stop rule on the job-wide done count, episode sums
+    all-reduced.  value = tables of the whole job x steps / the slowest rank's time."""
     import torch
     from pulselib_amd.environments.Poker import PokerAgentType, PokerGPU, PokerQNetwork, load_gpu_agents
     from pulselib_amd.scripts.trainGPU import train_agent_fused
     agents, types = load_gpu_agents(device, 9, AGENTS, 100, 13)
-    torch.manual_seed(SEED)
+    torch.manual_seed(SEED)                                                  # identical initial weights on every rank
     q = PokerQNetwork(None, device, gamma=.95, update_freq=20, state_dim=40, action_dim=13, learning_rate=2e-4, weight_decay=1e-5,
-                      seed=SEED)
+                      seed=SEED, table_id0=rank * tables)
     agents.insert(0, q)
     types.insert(0, PokerAgentType.QLEARNING)
     env = PokerGPU(device=device, agents=agents, n_players=10, max_players=10, n_games=tables, starting_bbs=100, max_bbs=1000,
-                   w1=.5, w2=.3, K=100, alpha=50, seed=SEED)
-    kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=False)
+                   w1=.5, w2=.3, K=100, alpha=50, seed=SEED, table_id0=rank * tables)
+    kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=world > 1)
     episodes = args.trainer_episodes if tables <= 262144 else max(3, args.trainer_episodes // 3)
     train_agent_fused(env, agents, types, 2, tables, device, **kw)          # warm-up episodes
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = train_agent_fused(env, agents, types, episodes, tables, device, **kw)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    steps = out["total_steps"] // tables
+    if dist is not None:                                                     # the slowest rank's clock
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_steps = out["total_steps"]                                         # job-wide (train_agent_fused counts the rule's n_global)
+    steps = total_steps // (tables * world)
+    weights = torch.cat([p.detach().reshape(-1) for p in q.network.parameters()]).double()
+    digest = [float(weights.sum()), float(weights.abs().sum())]
+    if dist is not None:                                                     # every rank must hold the same network after the run
+        lo = torch.tensor(digest + [-d for d in digest], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(lo, op=dist.ReduceOp.MAX)
+        same = bool(lo[0] == -lo[2]) and bool(lo[1] == -lo[3])
+    else:
+        same = True
     del env, q, agents
     torch.cuda.empty_cache()
-    return {"value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "ms_per_step": elapsed / max(steps, 1) * 1e3,
-            "tables": tables, "episodes": episodes, "steps": steps,
-            "learner": "PokerQNetwork 40-128-128-64-32-13, fp32 MFMA kernels (act + row lists, train, reduce + AdamW), acting and training every step",
+    return {"value": total_steps / elapsed, "unit": "env-steps/sec", "ms_per_step": elapsed / max(steps, 1) * 1e3,
+            "tables": tables * world, "tables_per_gpu": tables, "n_gpus": world, "episodes": episodes, "steps": steps,
+            "episode_reward_sums": out["episode_rewards"][:4], "weights_equal_on_all_ranks": same,
+            "learner": "PokerQNetwork 40-128-128-64-32-13, fp32 MFMA kernels (act + row lists, train, reduce + AdamW), acting and training every step"
+                       + ("" if world == 1 else "; data-parallel: gradient sum + row count all-reduced every step, identical AdamW step on every rank"),
             "counts_as": "n_games x steps incl. finished tables (trainGPU.py:108), episodes timed end to end incl. resets and the per-episode read-back",
             "reference_published": {"value": 2.5e7, "tables": 2000000, "hardware": "unnamed CUDA GPU",
                                     "source": "results/PokerGPU/runs/run_2.yaml:21,35 (BASELINE.md section 1)"}}
@@ -485,12 +522,25 @@ def main_rank(args):
         if dist is not None:
             dist.barrier()
 
-    def max_over_ranks(x: float) -> float:
+    def max_min_over_ranks(x: float):
+        """(max, min) over the ranks in ONE all-reduce (MAX of {x, -x})."""
         if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+            return x, x
+        t = torch.tensor([x, -x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        hi, lo = t.tolist()
+        return float(hi), float(-lo)
+
+    def max_over_ranks(x: float) -> float:
+        return max_min_over_ranks(x)[0]
+
+    def gather_over_ranks(x: float):
+        if dist is None:
+            return [x]
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+        t[rank] = x
+        dist.all_reduce(t)
+        return [float(v) for v in t.tolist()]
 
     from pulselib_amd.environments.Poker import PokerGPU
     from pulselib_amd.stoprule import LaggedDoneCount, RolloutTimer
@@ -522,7 +572,7 @@ def main_rank(args):
         timer.collect()
         if rank == 0:
             _log(f"active_players {mode}: timing blocks of {args.steps} steps ...")
-        blocks, episodes0 = [], loop.episode
+        blocks, fastest, own, episodes0 = [], [], [], loop.episode
         while True:
             barrier()
             torch.cuda.synchronize()
@@ -531,7 +581,8 @@ def main_rank(args):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0              # read BEFORE anything collective
             assert ran == args.steps
-            blocks.append(max_over_ranks(dt))           # identical on every rank: so is the decision below
+            hi, lo = max_min_over_ranks(dt)
+            blocks.append(hi); fastest.append(lo); own.append(dt)      # (hi is identical on every rank: so is the decision below)
             enough = sum(blocks) * 1e3 >= args.min_timed_ms and loop.episode - episodes0 >= args.min_episodes
             if enough or len(blocks) >= args.max_repeats:
                 break
@@ -545,9 +596,17 @@ def main_rank(args):
                           "max_ms": max(blocks) * 1e3, "sum_ms": sum(blocks) * 1e3,
                           "value_from_mean": total_tables * args.steps / statistics.fmean(blocks)},
                "episode_stats": stats.totals(),
+               # a straggling host shows here: per block the slowest and the fastest rank's time, and every rank's own sum
+               "rank_spread": {"slowest_over_fastest_mean": statistics.fmean(h / max(l, 1e-12) for h, l in zip(blocks, fastest)),
+                               "slowest_over_fastest_max": max(h / max(l, 1e-12) for h, l in zip(blocks, fastest)),
+                               "per_rank_sum_ms": [v * 1e3 for v in gather_over_ranks(sum(own))]},
+               "stop_rule": rule.stats() if hasattr(rule, "stats") else None,
                "roofline": roofline_record(args, N, sum_ms, n_launches, n_steps_timed, mode) if rank == 0 else None}
         if rank == 0:
             _log(f"active_players {mode}: {len(blocks)} blocks, {sum(blocks) * 1e3:.1f} ms, {rec['value']:.4g} env-steps/s")
+        if world > 1:                                        # every rank: a rehearsal's log shows that the ranks stayed in step
+            _log(f"rank {rank}/{world} active_players {mode}: episodes {loop.episode}, blocks {len(blocks)}, own time {sum(own) * 1e3:.1f} ms, "
+                 f"job totals {rec['episode_stats']}, stop rule {rec['stop_rule']}")
         return rec
 
     if rank == 0:
@@ -562,17 +621,22 @@ def main_rank(args):
         if rank == 0:
             _log("finished-tables census ...")
             census = finished_tables_census(args, device)
-    if args.trainer_loop == "on" or (args.trainer_loop == "auto" and solo):
+    if args.trainer_loop in ("on", "auto"):                  # auto: at every N (N > 1: the data-parallel learner, per-GPU size only)
+        rule.close()
         del env
         torch.cuda.empty_cache()
-        sizes = [args.tables] + ([args.trainer_tables_large] if args.trainer_tables_large and args.trainer_tables_large != args.tables else [])
+        sizes = [args.tables] + ([args.trainer_tables_large] if solo and args.trainer_tables_large and args.trainer_tables_large != args.tables else [])
         trainer = []
         for tables in sizes:
             if rank == 0:
-                _log(f"trainer-loop leg, {tables} tables ...")
-            trainer.append(trainer_loop_leg(args, device, tables))
+                _log(f"trainer-loop leg, {tables} tables per GPU x {world} ...")
+            trainer.append(trainer_loop_leg(args, device, tables, rank, world, dist))
             if rank == 0:
                 _log(f"trainer loop: {trainer[-1]['value']:.3g} env-steps/s")
+            if world > 1:
+                t = trainer[-1]
+                _log(f"rank {rank}/{world} trainer loop: episodes {t['episodes']}, steps {t['steps']}, first episode reward sums (job-wide) "
+                     f"{[round(x, 3) for x in t['episode_reward_sums']]}, weights equal on all ranks: {t['weights_equal_on_all_ranks']}")
     if (args.other_envs == "on" or (args.other_envs == "auto" and solo)) and rank == 0:
         _log("other environments ...")
         from tools.bench_envs import gpu_records
@@ -591,8 +655,14 @@ def main_rank(args):
                        "max_episode_steps": args.max_episode_steps, "steps_per_launch": CHECK_INTERVAL if not args.per_step_launches else 1,
                        "repeats": main["repeats"], "episodes_timed": main["episodes_timed"], "blocks": main["blocks"],
                        "episode_stats": main["episode_stats"], "min_timed_ms": args.min_timed_ms,
+                       # two check intervals per launch unless the rule fell back: a launch that waited in vain for its
+                       # host's verdict (a stalled rank) is counted here and the run goes on with one check interval per launch
+                       "paired_launches": bool(main["stop_rule"]["pairs"]) if main.get("stop_rule") else False,
+                       "verdict_timeouts": int(main["stop_rule"]["verdict_timeouts"]) if main.get("stop_rule") else 0,
+                       "rank_spread": main["rank_spread"],
                        "timed_window": "barrier, sync, t0, K steps, sync, dt (no barrier or collective between the clock reads); MAX over ranks",
-                       "parallelism": f"tables sharded x{world}, no data-path collective; stop-rule count + episode statistics all-reduced"},
+                       "parallelism": f"tables sharded x{world}, no data-path collective; stop-rule count exchanged per check point, episode "
+                                      f"statistics all-reduced every {REPORT_EVERY}th episode and at the end"},
             "roofline": main["roofline"], "trainer_loop": trainer, "finished_tables": census, "other_envs": other,
         }
         if len(modes) > 1:

@@ -204,7 +204,13 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
  * two-chunk launch needs belong to launches that have completed when it starts -- its first workgroup sums and
  * publishes them, the host answers with the launch's verdict word in pinned memory, and every wavefront reads the
  * relayed word before its first store (the launch then runs two chunks, one, or none).  Episodes come out step for
- * step as with one chunk per launch; the state is loaded and written back half as often. */
+ * step as with one chunk per launch; the state is loaded and written back half as often.
+ * That launch is the one place where device code waits for the host (the word arrives ~5 us after the launch starts).  The
+ * wait is bounded (PULSE_STOPRULE_OPT_VERDICT_WAIT_TICKS, 20 s by default) and the host decides by its own clock which side
+ * of the bound it is on: a host that is later than half the wait after the enqueue (a stalled rank, a stopped process) does
+ * NOT write the word, lets the launch give up -- it then runs nothing and stores nothing --, counts a time-out
+ * (pulse_stoprule_stats) and runs these and all further steps of the handle's life with one check interval per launch, which
+ * never waits in a kernel.  Same episodes either way.  Ranks that share one device (shm exchange) never pair. */
 int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView* v_odd, const uint8_t* agent_types,
                               uint64_t seed, uint64_t step_counter0, uint64_t table_id0, int64_t* actions,
                               float* rewards_even, float* rewards_odd, int32_t chunk_steps, int32_t max_steps, void* timer,
@@ -244,12 +250,29 @@ int pulse_stoprule_destroy(void* handle);
  * RCCL leg really ran). */
 int pulse_stoprule_mode(void* handle);
 int64_t pulse_stoprule_side_launches(void* handle);
+/* Options of a handle.  VERDICT_WAIT_TICKS: how long a paired launch (pulse_poker_rollout_until) waits for its host's verdict,
+ * in ticks of the device's 100 MHz clock (default 2,000,000,000 = 20 s; >= 100,000).  ALLOW_SHARED_DEVICE_PAIRS (0 / 1):
+ * with the shm exchange, ranks whose GPU (PCI bus id, told to the segment at create time) is also another rank's do not pair,
+ * since their launches wait for hosts that wait for every rank's launch to have started and the grids of several processes
+ * need not fit one device together; 1 lifts that for grids known to fit (tests).  DEBUG_LATE_VERDICTS (test hook): the next
+ * `value` verdicts are treated as "the host is too late": the launch gives up, the handle falls back.
+ * stats: out4 = {paired launches issued, verdict time-outs, 1 if the handle would still pair, side-stream check points}. */
+#define PULSE_STOPRULE_OPT_VERDICT_WAIT_TICKS        0
+#define PULSE_STOPRULE_OPT_ALLOW_SHARED_DEVICE_PAIRS 1
+#define PULSE_STOPRULE_OPT_DEBUG_LATE_VERDICTS       2
+int pulse_stoprule_set_option(void* handle, int32_t option, int64_t value);
+int pulse_stoprule_stats(void* handle, int64_t* out4);
 
 /* The shared-memory exchange of the stop rule as an object of its own (host code only; the rule creates one itself when
  * given shm_name).  Every rank maps the POSIX segment `name` (created by whoever comes first; unlink it once all ranks
  * have it mapped) and calls all_sum with the same sequence of indices 0, 1, 2, ...: *total = sum of the ranks' values. */
 int pulse_shm_create(const char* name, int32_t rank, int32_t world, void** handle);
 int pulse_shm_all_sum(void* handle, int64_t index, int64_t value, int64_t* total);
+/* The segment also carries one record per rank naming the GPU the rank computes on (any string equal exactly for ranks on
+ * one device; the rule stores the PCI bus id).  device_is_private: 1 = every rank has named its GPU within wait_ms and none
+ * shares this rank's, 0 otherwise. */
+int pulse_shm_set_device(void* handle, const char* bus_id);
+int pulse_shm_device_is_private(void* handle, int32_t wait_ms);
 int pulse_shm_destroy(void* handle);
 
 /* RCCL communicator of the job (one process per GPU), for the stop rule's 8-byte all-reduce on its side
@@ -330,7 +353,10 @@ typedef struct PulseQTable {
 /* Scratch of a shared table (NULL for private regions): caller-owned device memory, zero-initialised once.
  * count uint32[4]; cells uint64[n]; targets double[n]; owner int32[n]; acc_key uint64[acc_slots]; acc_cnt
  * uint32[acc_slots]; acc_sum double[acc_slots]; n >= n_boards; acc_slots a power of two >= 2 n.  launch_index: the
- * caller counts its update / rollout_step launches on this scratch (0, 1, 2, ...: its parity picks the list). */
+ * caller counts its update / rollout_step launches on this scratch (0, 1, 2, ...: its parity picks the list).
+ * A long list of deferred transitions is combined by 64 workgroups that meet inside the follow-up launch; if they cannot
+ * gather within wait_ticks (a co-tenant on the GPU) the meeting is called off as a whole, that launch's combined updates
+ * are dropped, and the next call on a shared table clears the accumulators and returns PULSE_EINTERNAL once. */
 typedef struct PulseQTableScratch {
     uint32_t* count;
     uint64_t* cells;
@@ -340,6 +366,9 @@ typedef struct PulseQTableScratch {
     uint32_t* acc_cnt;
     double* acc_sum;
     uint32_t n, acc_slots;
+    int64_t wait_ticks;             /* how long the follow-up launch's workgroups wait for each other (100 MHz ticks); 0 = 3 s */
+    int32_t debug_meet_extra;       /* test hook: arrivals that meeting expects beyond the grid's own (> 0: it never comes about) */
+    int32_t reserved0;
 } PulseQTableScratch;
 /* state lookup/insert + epsilon-greedy: actions int64[B] out, slots int64[B] out (-1 = no room: the region is full or
  * 4,096 consecutive slots were taken -- size a shared table for the states a run will visit; such a board acts at
@@ -403,8 +432,11 @@ int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row
  * pulse_qnet_slice_floats()] scratch (max_blocks = number of persistent workgroups, 256 = one per CU; a workgroup's
  * slice is laid out for its own stores, not in parameter order).  step: device int64 optimizer step count
  * (bias correction, target sync every update_freq steps).  stats: device fp32[4] scratch.  report: device fp32[4] out:
- * [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping, [3] 0 (-1: the reduce launch's workgroups did not
- * all arrive at their meeting within 5 s and no update was applied -- never observed).
+ * [0] rows trained on, [1] the MSE loss, [2] gradient norm before clipping, [3] 0, or -1: the reduce + AdamW launch's
+ * workgroups did not all gather within meet_wait_ticks (a co-tenant on the GPU), the meeting was called off AS A WHOLE and no
+ * parameter, moment or step count moved; the next pulse_qnet_train_* call then returns PULSE_EINTERNAL once.  The in-launch
+ * meeting is only used where the device holds the launch's whole grid at once (asked once per device), never with
+ * separate_apply = 1 (AdamW as a launch of its own, what pulse_qnet_train_grads / _apply always do).
  * Row filter: row_mask[r] != 0 (NULL: all) and states[r][12] in {0, 2} (:261); if no row passes, nothing changes (:262).
  * Trainer bookkeeping folded in (both optional, scripts/Poker/trainGPU.py:86,96): terminated (device uint8[n_rows],
  * NULL = skip) gets terminated[r] |= dones[r]; reward_sum (device double, NULL = skip) += sum of rewards over the
@@ -422,6 +454,10 @@ typedef struct PulseQNetTrain {
     int32_t* select_scratch;        /* device int32[select_words]: the row-selection launch's lists */
     int64_t select_words;           /* >= 259 * ceil(n_rows / 256) + 512 for the largest n_rows passed */
     int32_t select_from_act;        /* 1: the lists in select_scratch were written by pulse_qnet_act_select (see there) */
+    int32_t separate_apply;         /* 1: AdamW in a launch of its own (no in-launch meeting of the reduce launch's workgroups) */
+    int64_t meet_wait_ticks;        /* how long a workgroup waits at that meeting, in ticks of the 100 MHz clock; 0 = 5 s */
+    int32_t debug_meet_extra;       /* test hook: arrivals the meeting expects beyond the grid's own (> 0: it never comes about) */
+    int32_t reserved0;
 } PulseQNetTrain;
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions);
 int pulse_qnet_slice_floats(void);

@@ -66,7 +66,8 @@ class QNetTrain(C.Structure):
     _fields_ = [("net", QNet), ("target", QNet)] + [(n, C.c_void_p) for n in (
         "params", "target_params", "grad", "exp_avg", "exp_avg_sq", "step", "stats", "report", "partials")] + [(n, C.c_float) for n in (
             "lr", "weight_decay", "beta1", "beta2", "eps", "max_grad_norm", "gamma", "dropout_p")] + [
-        ("update_freq", C.c_int32), ("max_blocks", C.c_int32), ("select_scratch", C.c_void_p), ("select_words", C.c_int64), ("select_from_act", C.c_int32)]
+        ("update_freq", C.c_int32), ("max_blocks", C.c_int32), ("select_scratch", C.c_void_p), ("select_words", C.c_int64), ("select_from_act", C.c_int32),
+        ("separate_apply", C.c_int32), ("meet_wait_ticks", C.c_int64), ("debug_meet_extra", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class QTable(C.Structure):
@@ -75,7 +76,7 @@ class QTable(C.Structure):
 
 class QTableScratch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("count", "cells", "targets", "owner", "acc_key", "acc_cnt", "acc_sum")] + [
-        ("n", C.c_uint32), ("acc_slots", C.c_uint32)]
+        ("n", C.c_uint32), ("acc_slots", C.c_uint32), ("wait_ticks", C.c_int64), ("debug_meet_extra", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class BlackjackView(C.Structure):
@@ -111,8 +112,12 @@ SYMBOLS = {
     "pulse_stoprule_destroy": (C.c_int, [_P]),
     "pulse_stoprule_mode": (C.c_int, [_P]),
     "pulse_stoprule_side_launches": (_I64, [_P]),
+    "pulse_stoprule_set_option": (C.c_int, [_P, _I32, _I64]),
+    "pulse_stoprule_stats": (C.c_int, [_P, _P]),
     "pulse_shm_create": (C.c_int, [C.c_char_p, _I32, _I32, _P]),
     "pulse_shm_all_sum": (C.c_int, [_P, _I64, _I64, _P]),
+    "pulse_shm_set_device": (C.c_int, [_P, C.c_char_p]),
+    "pulse_shm_device_is_private": (C.c_int, [_P, _I32]),
     "pulse_shm_destroy": (C.c_int, [_P]),
     "pulse_comm_unique_id": (C.c_int, [_P]),
     "pulse_comm_create": (C.c_int, [_P, _I32, _I32, _P]),

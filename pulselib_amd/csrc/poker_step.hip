@@ -50,10 +50,10 @@ struct PolicyArgs {
     const uint32_t* carry2_partials; int carry2_n; long long* carry2_host; long long carry2_seq;
     uint32_t* wave_done_mid; int mid_step;
     const long long* verdict_host; long long* verdict_dev; long long verdict_id;
-    long long* verdict_err;                // pinned: set by a launch that gave up waiting for its verdict (the host then fails the call)
+    long long* verdict_err;                // pinned: set by a launch that gave up waiting for its verdict (the host then runs its steps unpaired)
+    long long verdict_ticks;               // ticks of the 100 MHz wall clock thread 0 waits for the word: a launch never waits for a dead host for ever
 };
 constexpr int kVerdictStride = 16;                          // long longs between the 64 copies of a relayed verdict word (one 128-byte line each)
-constexpr long long kVerdictSpinTicks = 2000000000ll;     // 20 s of the 100 MHz wall clock: a launch never waits for a dead host for ever
 struct ChunkArgs {                         // MULTI only: the odd steps' output buffers and the number of steps
     float* obs_odd;
     float* rewards_odd;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 for (;;) {
                     const long long w = __hip_atomic_load(pa.verdict_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((w >> 8) == pa.verdict_id) { flags = (int)(w & 0xFF); break; }
-                    if (wall_clock64() - t0 > kVerdictSpinTicks) {                             // error: run nothing, and tell the host
+                    if (wall_clock64() - t0 > pa.verdict_ticks) {                              // too late: run nothing, and tell the host
                         flags = 0x81;
                         if (pa.verdict_err) __hip_atomic_store(pa.verdict_err, pa.verdict_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
         for (;;) {
             w = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((w >> 8) == pa.verdict_id) break;
-            if (wall_clock64() - t0 > 2 * kVerdictSpinTicks) { w = 0x81; break; }
+            if (wall_clock64() - t0 > 2 * pa.verdict_ticks + 100000000ll) { w = 0x81; break; }
             __builtin_amdgcn_s_sleep(32);
         }
         const int flags = __builtin_amdgcn_readfirstlane((int)w);
@@ -1047,6 +1047,7 @@ void launch_pair(const PulsePokerView& v_even, const PulsePokerView& v_odd, uint
     }
     pa.wave_done_mid = plan.wave_done_mid; pa.mid_step = plan.n_chunks == 2 ? chunk_steps : 0;
     pa.verdict_host = plan.verdict_host; pa.verdict_dev = plan.verdict_dev; pa.verdict_id = plan.launch_id; pa.verdict_err = plan.verdict_err;
+    pa.verdict_ticks = plan.wait_ticks;
     const ChunkArgs ca{v_odd.obs, rewards_odd, n_steps};
     launch_chunk(v_even, actions, rewards_even, pa, ca, st);
 }
@@ -1110,6 +1111,7 @@ int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView
     const bool per_step = (v_even->flags & PULSE_VIEW_NO_CHUNK) != 0;
     PulseStopRule* rule = static_cast<PulseStopRule*>(stoprule);
     int done = 0, parity = 0, verdict = 0;
+    bool fell_back = false;
     // ---- paired launches: with the lag-1 rule ONE launch runs up to two check intervals and takes the rule's verdicts on
     // the two check points before them itself (pulse_internal.h: StopRulePair) -- half as many state load bursts and
     // store tails per episode, the same episodes step for step.  (PULSE_VIEW_NO_PAIRS / lag 0 / lag 2 / RCCL: one check
@@ -1133,8 +1135,12 @@ int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView
                         parity ? rewards_odd : rewards_even, parity ? rewards_even : rewards_odd, n, chunk_steps, plan, st);
             if (int rc = pulse::finish_launch("pulse_poker_rollout_until")) return rc;
             if (int rc = pulse::stoprule_pair_commit(rule, &plan, n_waves_chunk, st)) return rc;
-            int chunks_run = 0;
-            if (int rc = pulse::stoprule_pair_verdict(rule, &plan, &chunks_run, &verdict)) return rc;
+            int chunks_run = 0, gave_up = 0;
+            if (int rc = pulse::stoprule_pair_verdict(rule, &plan, &chunks_run, &verdict, &gave_up)) return rc;
+            if (gave_up) {                  // the host was too late for this launch: it ran nothing; the rule pairs no more
+                fell_back = !verdict;       // (unless the episode had ended before it anyway) its steps run below, one check interval per launch
+                break;
+            }
             const int ran = chunks_run == k ? n : chunks_run * chunk_steps;
             done += ran; parity ^= ran & 1;
             if (tm && tm->open) {
@@ -1142,9 +1148,11 @@ int pulse_poker_rollout_until(const PulsePokerView* v_even, const PulsePokerView
                 if (tm->open_launches >= kTimedSpan) timer_end(tm, st);
             }
         }
-        if (tm && tm->open) timer_end(tm, st);
-        *steps_done = done; *over = verdict;
-        return 0;
+        if (!fell_back) {
+            if (tm && tm->open) timer_end(tm, st);
+            *steps_done = done; *over = verdict;
+            return 0;
+        }
     }
     while (done < max_steps && !verdict) {
         const int n = chunk_steps < max_steps - done ? chunk_steps : max_steps - done;

@@ -40,7 +40,8 @@ struct StopRulePair {
     StopRuleCarry carry[2];       // check points a - 2 and a - 1, where still unpublished
     const long long* verdict_host;
     long long* verdict_dev;
-    long long* verdict_err;       // pinned word a launch sets when it gave up waiting (the next claim fails the call)
+    long long* verdict_err;       // pinned word a launch sets when it gave up waiting
+    long long wait_ticks;         // how long the launch waits for its verdict (100 MHz ticks from its start)
     long long launch_id;
     long long first_check_point;  // a
     int n_chunks;                 // k
@@ -50,6 +51,7 @@ bool stoprule_pairs_supported(const PulseStopRule* h, int n_partials);
 int stoprule_pair_claim(PulseStopRule* h, int n_partials, int n_chunks, StopRulePair* plan);
 int stoprule_pair_commit(PulseStopRule* h, const StopRulePair* plan, int n_partials, ihipStream_t* stream);
 // After the launch was enqueued: waits for the counts it carries, writes its verdict word, tells how many of its chunks run.
-int stoprule_pair_verdict(PulseStopRule* h, const StopRulePair* plan, int* chunks_run, int* over);
+// *gave_up = 1: the host was too late, the launch ran nothing, the handle is back before it and pairs no more (stoprule.hip).
+int stoprule_pair_verdict(PulseStopRule* h, const StopRulePair* plan, int* chunks_run, int* over, int* gave_up);
 
 }  // namespace pulse

@@ -1303,7 +1303,11 @@ struct ReduceArgs {
     long long* step; double* reward_sum;      // reward_sum: nullptr or += sum of rewards over row_mask rows
     const float* win_reward; int n_windows;   // the select launch's per-window reward sums
     unsigned* meet;                           // fused form: [0..8) arrival counters (zero at launch), [8 + b] workgroup b's sum of g^2
+    long long wait_ticks;                     // fused form: how long a workgroup waits at the meeting (100 MHz ticks)
+    unsigned extra_arrivals;                  // fused form, test hook: arrivals counter 0 expects beyond the grid's (never met)
+    long long* gave_up;                       // fused form: pinned host word, += 1 by a launch whose meeting was called off
 };
+constexpr unsigned kMeetOff = 0x80000000u;     // an arrival counter with this bit set: the meeting was called off
 
 struct AdamArgs {
     float* params; float* target; const float* grad; float* m; float* v; const long long* step; float* scal; float* report;
@@ -1431,12 +1435,27 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     }
     if (FUSED) {
         if (threadIdx.x < 64) {                                   // wavefront 0: lanes 0..7 watch one counter each
-            const unsigned want = (gridDim.x + 7 - (threadIdx.x & 7)) / 8;      // workgroups b with b % 8 == lane
-            bool met = true;
+            // The meeting is all or nothing.  "Go" = all eight counters read exactly full.  A workgroup whose wait runs out
+            // calls the meeting off by setting kMeetOff in a counter that is still short -- with a compare-and-swap from the
+            // value it read, so the bit lands either before the missing arrival (that counter never reads full again: nobody
+            // goes, before or after) or not at all (the counter moved: look again).  A full counter is never marked, a marked
+            // one never reads full: no workgroup can apply its part of the update while another skips its own.
+            unsigned want = (gridDim.x + 7 - (threadIdx.x & 7)) / 8;            // workgroups b with b % 8 == lane
+            if (threadIdx.x == 0) want += a.extra_arrivals;
+            bool met = false;
             for (const long long t0 = wall_clock64();;) {
                 const unsigned got = threadIdx.x < 8 ? __hip_atomic_load(a.meet + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-                if (__ballot(got < want) == 0ull) break;
-                if (wall_clock64() - t0 > 500000000ll) { met = false; break; }   // 5 s of the 100 MHz clock: never seen; no update then
+                if (__ballot((got & kMeetOff) != 0u) != 0ull) break;
+                const unsigned long long short_of = __ballot(got != want);
+                if (short_of == 0ull) { met = true; break; }
+                if (wall_clock64() - t0 > a.wait_ticks) {
+                    const int first = __ffsll((long long)short_of) - 1;
+                    unsigned mine = 0u;
+                    if ((int)threadIdx.x == first)
+                        mine = atomicCAS(a.meet + threadIdx.x, got, got | kMeetOff) == got ? 1u : 0u;
+                    if (__ballot(mine != 0u) != 0ull) break;
+                    continue;                                      // the counter moved under the mark: read it again
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
             float tot = 0.0f;                                      // the same order in every workgroup: the update does not depend on timing
@@ -1444,7 +1463,13 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
                 tot += __hip_atomic_load(reinterpret_cast<float*>(a.meet + 8 + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
-            if (threadIdx.x == 0) { bc[0] = tot; bc[1] = met ? rows : 0.0f; if (!met) w.report[3] = -1.0f; }
+            if (threadIdx.x == 0) {
+                bc[0] = tot; bc[1] = met ? rows : 0.0f;
+                if (blockIdx.x == 0) {
+                    w.report[3] = met ? 0.0f : -1.0f;
+                    if (!met && a.gave_up) __hip_atomic_fetch_add(a.gave_up, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
         __syncthreads();
         const float total_ss = bc[0], count = bc[1];
@@ -1473,6 +1498,30 @@ __global__ __launch_bounds__(256) void qnet_adamw_kernel(const AdamArgs a) {
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// The fused reduce + AdamW launch is a meeting of all its workgroups inside one ordinary launch: it is only taken where the
+// device can hold the whole grid at once (asked once per device; a smaller part, e.g. a CPX partition, gets the two-launch
+// form), and a meeting that does not come about -- a co-tenant holding the CUs -- is called off as a whole, counted in
+// this pinned word and reported by the next call (PULSE_EINTERNAL once; nothing was updated, training may go on).
+long long* g_meet_gave_up = nullptr;
+long long g_meet_gave_up_seen = 0;
+bool fused_apply_fits(unsigned grid) {
+    static int resident[64] = {0};                                 // per device: 0 = not asked yet, -1 = unknown
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (resident[dev] == 0) {
+        int per_cu = 0; hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qnet_grad_reduce_kernel<true>, 256, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, dev) == hipSuccess) resident[dev] = std::max(per_cu * prop.multiProcessorCount, 1);
+        else { (void)hipGetLastError(); resident[dev] = -1; }
+    }
+    if (!g_meet_gave_up) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+        g_meet_gave_up = static_cast<long long*>(p); *g_meet_gave_up = 0;
+    }
+    return resident[dev] >= (int)grid;
+}
 
 int launch(const QNetArgs& a, void* stream) {
     const PulseQNet& n = a.net;
@@ -1622,6 +1671,15 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     hipStream_t st = (hipStream_t)stream;
     const unsigned eg = (unsigned)((np + 255) / 256);
     bool fused = false;
+    if (g_meet_gave_up) {
+        const long long n = __atomic_load_n(g_meet_gave_up, __ATOMIC_ACQUIRE);
+        if (n != g_meet_gave_up_seen) {
+            g_meet_gave_up_seen = n;
+            return pulse::fail(PULSE_EINTERNAL, "pulse_qnet_train_step: an earlier reduce + AdamW launch could not gather its workgroups within its wait "
+                                                "(another process or stream holds the GPU's compute units?) and applied NO update (report[3] = -1); "
+                                                "set PulseQNetTrain.separate_apply to run AdamW as a launch of its own");
+        }
+    }
     if (grads && n_rows > 0) {
         TrainArgs a{};
         a.net = FlatNet{t->params, n.state_dim, n.n_actions}; a.tgt = FlatNet{t->target_params, n.state_dim, n.n_actions}; a.partials = t->partials; a.scal = t->stats; a.n_params = np; a.states = states; a.stride = row_stride;
@@ -1672,9 +1730,13 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
     r.reward_sum = reward_sum; r.win_reward = win_reward; r.n_windows = n_windows; r.meet = a.meet;
-    fused = apply;                                             // one GPU: AdamW rides in the reduce launch
     AdamArgs b = adam_args(t, np);
     const unsigned rg = (unsigned)((kSliceStats + 127) / 128);
+    // one GPU: AdamW rides in the reduce launch -- where the whole grid fits the device at once
+    fused = apply && !t->separate_apply && fused_apply_fits(rg);
+    r.wait_ticks = t->meet_wait_ticks > 0 ? (long long)t->meet_wait_ticks : 500000000ll;     // 5 s of the 100 MHz clock
+    r.extra_arrivals = t->debug_meet_extra > 0 ? (unsigned)t->debug_meet_extra : 0u;
+    r.gave_up = g_meet_gave_up;
     if (fused) hipLaunchKernelGGL(qnet_grad_reduce_kernel<true>, dim3(rg), dim3(256), 0, st, r, b);
     else hipLaunchKernelGGL(qnet_grad_reduce_kernel<false>, dim3(rg), dim3(256), 0, st, r, b);
     }

@@ -113,7 +113,11 @@ struct Deferred {                 // per-launch scratch, owned by the caller (Pu
     double* acc_sum;              // [acc_slots]
     unsigned int acc_slots;       // power of two >= 2 n
     int parity;
+    long long wait_ticks;         // how long a workgroup of the follow-up launch waits at its meeting (100 MHz ticks)
+    unsigned int extra_arrivals;  // test hook: arrivals the meeting expects beyond the grid's (never met)
+    long long* gave_up;           // pinned host word, += 1 by a follow-up launch whose meeting was called off
 };
+constexpr unsigned int kDeferOff = 0x80000000u;   // the meeting counter with this bit: called off
 
 // q[s][a] <- q + alpha (target - q): race-free regions write, shared tables try ONE compare-and-swap and defer on a loss
 __device__ __forceinline__ void apply_update(Entry* table, long long s, int a, double target, double alpha, bool shared_table, const Deferred& d) {
@@ -175,14 +179,35 @@ __global__ __launch_bounds__(kBlock) void qtable_defer_kernel(Entry* table, Defe
     }
     __threadfence();
     __syncthreads();
-    if (!solo && threadIdx.x == 0) {
-        unsigned int* meet = d.count + 2 + d.parity;
-        atomicAdd(meet, 1u);
-        const long long t0 = wall_clock64();          // (100 MHz; a wait that outlasts 3 s gives up rather than hang the device)
-        while (__hip_atomic_load(meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && wall_clock64() - t0 < 300000000ll)
-            __builtin_amdgcn_s_sleep(8);
+    if (!solo) {
+        // All or nothing: phase 2 runs iff the counter read exactly full.  A workgroup whose wait runs out marks the counter
+        // (compare-and-swap from the short value it read: the mark lands before the missing arrival or not at all), after
+        // which it never reads full: no owner applies `sum / k` from accumulators other workgroups are still adding to.
+        // The accumulators then stay claimed; the host finds the pinned count changed, clears them and fails its next call.
+        __shared__ int go_s;
+        if (threadIdx.x == 0) {
+            unsigned int* meet = d.count + 2 + d.parity;
+            const unsigned int want = gridDim.x + d.extra_arrivals;
+            atomicAdd(meet, 1u);
+            int go = 0;
+            for (const long long t0 = wall_clock64();;) {        // (100 MHz)
+                const unsigned int got = __hip_atomic_load(meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got & kDeferOff) break;
+                if (got == want) { go = 1; break; }
+                if (wall_clock64() - t0 > d.wait_ticks) {
+                    if (atomicCAS(meet, got, got | kDeferOff) == got) {
+                        if (d.gave_up) __hip_atomic_fetch_add(d.gave_up, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            go_s = go;
+        }
+        __syncthreads();
+        if (!go_s) return;
     }
-    __syncthreads();
     __threadfence();
     for (unsigned int i = first; i < n; i += stride) {
         const int h = d.owner[i];
@@ -300,16 +325,40 @@ int check_table(const PulseQTable* q, int32_t n_boards, int32_t n) {
     return 0;
 }
 
+// A follow-up launch whose workgroups did not gather (a co-tenant on the GPU) drops that launch's combined updates and
+// leaves their accumulators claimed: counted in this pinned word; the next call on a shared table clears the accumulators
+// it is handed and fails once (PULSE_EINTERNAL), after which the table is usable again.
+long long* g_defer_gave_up = nullptr;
+long long g_defer_gave_up_seen = 0;
+
 // the shared table's scratch, checked and turned into the kernels' view of it
-int deferred_of(const PulseQTable* q, const PulseQTableScratch* sc, int32_t n_boards, uint64_t launch_index, Deferred* d) {
+int deferred_of(const PulseQTable* q, const PulseQTableScratch* sc, int32_t n_boards, uint64_t launch_index, Deferred* d, hipStream_t st) {
     *d = Deferred{};
     if (q->region_slots) return 0;                      // private regions: no race, no scratch
     if (!sc || !sc->count || !sc->cells || !sc->targets || !sc->owner || !sc->acc_key || !sc->acc_cnt || !sc->acc_sum)
         return pulse::fail(PULSE_EINVAL, "PulseQTable: a shared table needs its PulseQTableScratch");
     if (sc->n < (uint32_t)n_boards || sc->acc_slots < 2u * (uint32_t)n_boards || (sc->acc_slots & (sc->acc_slots - 1u)))
         return pulse::fail(PULSE_EINVAL, "PulseQTableScratch: need n >= n_boards and acc_slots a power of two >= 2 n_boards");
+    if (!g_defer_gave_up) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
+            return pulse::fail_hip((int)hipGetLastError(), "PulseQTable: pinned word of the follow-up launch");
+        g_defer_gave_up = static_cast<long long*>(p); *g_defer_gave_up = 0;
+    }
+    const long long gone = __atomic_load_n(g_defer_gave_up, __ATOMIC_ACQUIRE);
+    if (gone != g_defer_gave_up_seen) {
+        g_defer_gave_up_seen = gone;
+        (void)hipMemsetAsync(sc->acc_key, 0, (size_t)sc->acc_slots * sizeof(uint64_t), st);
+        (void)hipMemsetAsync(sc->acc_cnt, 0, (size_t)sc->acc_slots * sizeof(uint32_t), st);
+        (void)hipMemsetAsync(sc->acc_sum, 0, (size_t)sc->acc_slots * sizeof(double), st);
+        return pulse::fail(PULSE_EINTERNAL, "PulseQTable: the follow-up launch of an earlier update could not gather its workgroups within its wait "
+                                            "(another process or stream on the GPU?); that launch's combined updates were dropped, the scratch's "
+                                            "accumulators have been cleared");
+    }
     *d = Deferred{sc->count, reinterpret_cast<unsigned long long*>(sc->cells), sc->targets, sc->owner,
-                  reinterpret_cast<unsigned long long*>(sc->acc_key), sc->acc_cnt, sc->acc_sum, sc->acc_slots, (int)(launch_index & 1u)};
+                  reinterpret_cast<unsigned long long*>(sc->acc_key), sc->acc_cnt, sc->acc_sum, sc->acc_slots, (int)(launch_index & 1u),
+                  sc->wait_ticks > 0 ? (long long)sc->wait_ticks : 300000000ll, sc->debug_meet_extra > 0 ? (unsigned int)sc->debug_meet_extra : 0u,
+                  g_defer_gave_up};
     return 0;
 }
 void launch_deferred(Entry* table, const Deferred& d, double alpha, hipStream_t st) {
@@ -341,7 +390,7 @@ int pulse_qtable_update(const PulseQTable* q, const PulseQTableScratch* scratch,
         return pulse::fail(PULSE_EINVAL, "pulse_qtable_update: null argument");
     if (n_boards == 0) return 0;
     Deferred d;
-    if (int rc = deferred_of(q, scratch, n_boards, launch_index, &d)) return rc;
+    if (int rc = deferred_of(q, scratch, n_boards, launch_index, &d, (hipStream_t)stream)) return rc;
     Entry* table = static_cast<Entry*>(q->entries);
     hipLaunchKernelGGL(qtable_update_kernel, dim3((n_boards + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
                        table, q->capacity, q->region_slots, slots, actions, rewards, next_boards, terminal, n_boards, n * n, alpha, gamma, d);
@@ -359,7 +408,7 @@ int pulse_qtable_rollout_step(const PulseQTable* q, const PulseQTableScratch* sc
     if (env_step == 0) return pulse::fail(PULSE_EINVAL, "pulse_qtable_rollout_step: env_step must be >= 1 (0 is the reset draw)");
     if (n_boards == 0) return 0;
     Deferred d;
-    if (int rc = deferred_of(q, scratch, n_boards, launch_index, &d)) return rc;
+    if (int rc = deferred_of(q, scratch, n_boards, launch_index, &d, (hipStream_t)stream)) return rc;
     Entry* table = static_cast<Entry*>(q->entries);
     const dim3 grid((n_boards + kBlock - 1) / kBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;

@@ -148,13 +148,15 @@ struct ShmRecord { long long count, seq, pad[6]; };
 
 // The exchange as an object of its own (host code only: usable, and tested, without a GPU).  all_sum(index, value):
 // every rank calls it with the same sequence of indices; returns the sum of the ranks' values for that index.
-struct PulseShm { ShmRecord* mem; size_t bytes; int rank, world; };
+// ... followed by one 64-byte record per rank naming the GPU the rank computes on (PCI bus id; empty = not told yet)
+struct ShmDevice { char bus_id[56]; long long set; };
+struct PulseShm { ShmRecord* mem; size_t bytes; int rank, world; ShmDevice* devices; };
 
 extern "C" {
 
 int pulse_shm_create(const char* name, int32_t rank, int32_t world, void** out) {
     if (!name || !out || world < 1 || rank < 0 || rank >= world) return pulse::fail(PULSE_EINVAL, "pulse_shm_create: bad argument");
-    PulseShm* h = new PulseShm{nullptr, (size_t)world * kSlots * sizeof(ShmRecord), rank, world};
+    PulseShm* h = new PulseShm{nullptr, (size_t)world * kSlots * sizeof(ShmRecord) + (size_t)world * sizeof(ShmDevice), rank, world, nullptr};
     // Whoever comes first creates the segment (O_EXCL: a fresh, zero-filled one, seq 0 = nothing published); the others
     // open it.  A stale segment of that name (a crashed job whose rank-0 pid was reused) would carry old sequence
     // numbers: the host code removes the name before it tells the ranks (stoprule.py: _shared_name), and the name
@@ -166,8 +168,40 @@ int pulse_shm_create(const char* name, int32_t rank, int32_t world, void** out) 
     close(fd);
     if (m == MAP_FAILED) { delete h; return pulse::fail(PULSE_EINTERNAL, "pulse_shm_create: mmap failed"); }
     h->mem = static_cast<ShmRecord*>(m);             // a fresh segment is zero-filled: seq 0 = nothing published
+    h->devices = reinterpret_cast<ShmDevice*>(h->mem + (size_t)world * kSlots);
     *out = h;
     return 0;
+}
+
+/* Names the GPU this rank computes on (any string that is equal exactly for ranks on the same device: the PCI bus id). */
+int pulse_shm_set_device(void* handle, const char* bus_id) {
+    PulseShm* h = static_cast<PulseShm*>(handle);
+    if (!h || !bus_id) return pulse::fail(PULSE_EINVAL, "pulse_shm_set_device: null argument");
+    ShmDevice* d = h->devices + h->rank;
+    std::memset(d->bus_id, 0, sizeof d->bus_id);
+    std::strncpy(d->bus_id, bus_id, sizeof d->bus_id - 1);
+    __atomic_store_n(&d->set, 1ll, __ATOMIC_RELEASE);
+    return 0;
+}
+
+/* 1: every rank has named its GPU and no other rank shares this rank's; 0: another rank computes on the same GPU (or a rank
+ * has not named its own within wait_ms) -- launches that wait for each other's hosts must then not be used. */
+int pulse_shm_device_is_private(void* handle, int32_t wait_ms) {
+    PulseShm* h = static_cast<PulseShm*>(handle);
+    if (!h) return pulse::fail(PULSE_EINVAL, "pulse_shm_device_is_private: null argument");
+    const ShmDevice* mine = h->devices + h->rank;
+    if (!__atomic_load_n(&mine->set, __ATOMIC_ACQUIRE)) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < h->world; ++r) {
+        if (r == h->rank) continue;
+        const ShmDevice* d = h->devices + r;
+        while (!__atomic_load_n(&d->set, __ATOMIC_ACQUIRE)) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(wait_ms)) return 0;
+            usleep(200);
+        }
+        if (std::strncmp(d->bus_id, mine->bus_id, sizeof d->bus_id) == 0) return 0;
+    }
+    return 1;
 }
 
 int pulse_shm_all_sum(void* handle, int64_t index, int64_t value, int64_t* total) {
@@ -228,6 +262,16 @@ struct PulseStopRule {
     long long launches;                   // paired launches issued so far (ids start at 1)
     long long verdicts_known;             // check points below this index have been read and did not end the episode ...
     bool over_known;                      // ... unless this is set: check point verdicts_known - 1 did
+    long long global_known[kSlots], global_known_idx[kSlots];   // job-wide counts already summed over the ranks (never summed twice)
+    // a paired launch waits for its host's verdict at most verdict_wait_ticks (100 MHz); a host that finds itself later than
+    // half of that lets the launch give up (it runs nothing), counts a time-out and goes on with one check interval per launch
+    long long verdict_wait_ticks;
+    long long verdict_timeouts;
+    bool pairs_off;                       // set by a time-out, for the life of the handle
+    int device_private;                   // shm exchange: -1 = not asked yet, 0 = another rank shares this GPU (no pairs), 1 = no
+    bool allow_shared_device_pairs;
+    int debug_late;                       // test hook: that many coming verdicts are treated as "host too late"
+    std::chrono::steady_clock::time_point pair_enqueued;
 };
 
 namespace {
@@ -308,8 +352,18 @@ int stoprule_commit(PulseStopRule* h, int n_partials, hipStream_t st) {
 
 
 // ---- paired launches (pulse_internal.h: StopRulePair)
-bool stoprule_pairs_supported(const PulseStopRule* h, int n_partials) {
-    return h && h->lag == 1 && h->mode != kModeRccl && n_partials > 0 && n_partials <= h->max_partials;
+// Ranks that share ONE device must not pair (shm exchange): a paired launch waits for its host, the host for every rank's
+// launch to have STARTED (their first workgroups publish the counts it needs), and the grids of several processes need not
+// fit the device together -- the resident wavefronts of one rank would spin while the other rank's first workgroup cannot be
+// scheduled.  One check interval per launch never waits inside a kernel.
+bool stoprule_pairs_supported(const PulseStopRule* h_, int n_partials) {
+    PulseStopRule* h = const_cast<PulseStopRule*>(h_);
+    if (!(h && h->lag == 1 && h->mode != kModeRccl && !h->pairs_off && n_partials > 0 && n_partials <= h->max_partials)) return false;
+    if (h->mode == kModeShm && !h->allow_shared_device_pairs) {
+        if (h->device_private < 0) h->device_private = pulse_shm_device_is_private(h->shm, 20000) == 1 ? 1 : 0;
+        if (!h->device_private) return false;
+    }
+    return true;
 }
 
 namespace {
@@ -320,6 +374,7 @@ int pair_count(PulseStopRule* h, long long c, bool* over) {
     const int slot = (int)(c % kSlots);
     long long glob = h->host[slot].global;
     if (h->mode == kModeShm) { int64_t total = 0; if (int rc = pulse_shm_all_sum(h->shm, c, h->host[slot].local, &total)) return rc; glob = total; }
+    h->global_known[slot] = glob; h->global_known_idx[slot] = c;
     *over = (double)glob > h->threshold * (double)h->n_global;
     h->verdicts_known = c + 1; h->over_known = *over;
     return 0;
@@ -341,6 +396,7 @@ int stoprule_pair_claim(PulseStopRule* h, int n_partials, int n_chunks, StopRule
     plan->verdict_host = h->verdict_host + (plan->launch_id % kSlots);
     plan->verdict_dev = h->verdict_dev + (plan->launch_id % kSlots) * kVerdictCopies * kVerdictStride;
     plan->verdict_err = h->verdict_host + kSlots;
+    plan->wait_ticks = h->verdict_wait_ticks;
     uint32_t* first = h->partials_dev + (size_t)(a % kSlots) * h->max_partials;
     uint32_t* second = h->partials_dev + (size_t)((a + 1) % kSlots) * h->max_partials;
     plan->wave_done_mid = n_chunks == 2 ? first : nullptr;
@@ -360,14 +416,41 @@ int stoprule_pair_commit(PulseStopRule* h, const StopRulePair* plan, int n_parti
     for (int i = 0; i < plan->n_chunks; ++i) h->n_partials[(plan->first_check_point + i) % kSlots] = n_partials;
     h->last_stream = st;
     h->submitted = plan->first_check_point + plan->n_chunks;
+    h->pair_enqueued = std::chrono::steady_clock::now();
     return 0;
 }
 
-int stoprule_pair_verdict(PulseStopRule* h, const StopRulePair* plan, int* chunks_run, int* over) {
+// The verdict of one paired launch.  *gave_up = 1: the host was too late for the launch (see below), which therefore ran
+// NOTHING and left no trace; the handle has been set back to before the launch and no longer pairs -- the caller runs the
+// same steps with one check interval per launch (`over` still tells whether the episode had ended before them).
+int stoprule_pair_verdict(PulseStopRule* h, const StopRulePair* plan, int* chunks_run, int* over, int* gave_up) {
     const long long a = plan->first_check_point;
     bool skip = false, stop = false;
+    *gave_up = 0;
     if (a - 2 >= h->epoch_first) if (int rc = pair_count(h, a - 2, &skip)) return rc;
     if (!skip && a - 1 >= h->epoch_first) if (int rc = pair_count(h, a - 1, &stop)) return rc;
+    // The launch waits wait_ticks (of its 100 MHz clock) from its start for this word, then gives up.  Who decides whether
+    // it got it?  The host, by its own clock, BEFORE writing: the launch cannot have started before it was enqueued, so up
+    // to half the wait after the enqueue the word certainly arrives in time and is written; later than that (a rank of the
+    // job stalled, this process was stopped) the word is NOT written and the host waits for the launch's give-up mark.
+    // Either way both sides agree on what ran -- no word and mark crossing each other.
+    const double wait_s = (double)plan->wait_ticks * 1e-8;
+    const double late_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->pair_enqueued).count();
+    bool late = late_s > 0.5 * wait_s;
+    if (h->debug_late > 0) { --h->debug_late; late = true; }
+    if (late) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(plan->verdict_err, __ATOMIC_ACQUIRE) != plan->launch_id) {
+            usleep(100);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0 * wait_s + 5.0)
+                return fail(PULSE_EINTERNAL, "stop rule: a paired launch neither took its verdict nor gave up (is the device gone?)");
+        }
+        __atomic_store_n(plan->verdict_err, 0ll, __ATOMIC_RELEASE);
+        ++h->verdict_timeouts; h->pairs_off = true;
+        h->submitted = a;                                   // the launch's check points were never counted
+        *chunks_run = 0; *over = skip ? 1 : 0; *gave_up = 1;
+        return 0;
+    }
     // (stop_mid only means something to a launch of two chunks; a one-chunk launch whose chunk is the episode's last runs it)
     const long long word = (plan->launch_id << 8) | (skip ? 1 : 0) | (stop && plan->n_chunks == 2 ? 2 : 0);
     __atomic_store_n(const_cast<long long*>(plan->verdict_host), word, __ATOMIC_RELEASE);
@@ -387,6 +470,9 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
     PulseStopRule* h = new PulseStopRule();
     std::memset(h, 0, sizeof *h);
     h->n_local = n_local; h->n_global = n_global; h->threshold = threshold; h->lag = lag;
+    h->verdict_wait_ticks = 2000000000ll;                   // 20 s
+    h->device_private = -1;
+    for (int i = 0; i < kSlots; ++i) h->global_known_idx[i] = -1;
     h->comm = static_cast<PulseComm*>(comm); h->rank = rank; h->world = world;
     // a communicator is honoured whatever its size: a world of one is a valid all-reduce, and it is what a one-GPU box
     // can run of the side-stream path (event hand-over, sum, ncclAllReduce, publish)
@@ -419,6 +505,12 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
         void* shm = nullptr;
         if (int rc = pulse_shm_create(shm_name, rank, world, &shm)) { (void)pulse_stoprule_destroy(h); return rc; }
         h->shm = static_cast<PulseShm*>(shm);
+        int dev = 0; char bus[64] = {0};
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            std::snprintf(bus, sizeof bus, "unknown-device");     // equal for every rank that could not tell: treated as shared
+        }
+        (void)pulse_shm_set_device(shm, bus);
     }
     *out = h;
     return 0;
@@ -448,6 +540,28 @@ int pulse_stoprule_mode(void* handle) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_mode: null argument");
     return h->mode;
+}
+
+int pulse_stoprule_set_option(void* handle, int32_t option, int64_t value) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_set_option: null handle");
+    switch (option) {
+    case PULSE_STOPRULE_OPT_VERDICT_WAIT_TICKS:
+        if (value < 100000) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_set_option: the verdict wait must be at least 1 ms (100,000 ticks)");
+        h->verdict_wait_ticks = value; return 0;
+    case PULSE_STOPRULE_OPT_ALLOW_SHARED_DEVICE_PAIRS: h->allow_shared_device_pairs = value != 0; return 0;
+    case PULSE_STOPRULE_OPT_DEBUG_LATE_VERDICTS: h->debug_late = (int)value; return 0;
+    default: return pulse::fail(PULSE_EINVAL, "pulse_stoprule_set_option: unknown option");
+    }
+}
+
+int pulse_stoprule_stats(void* handle, int64_t* out4) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h || !out4) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_stats: null argument");
+    out4[0] = h->launches; out4[1] = h->verdict_timeouts;
+    out4[2] = pulse::stoprule_pairs_supported(h, 1) ? 1 : 0;
+    out4[3] = h->side_launches;
+    return 0;
 }
 
 int64_t pulse_stoprule_side_launches(void* handle) {
@@ -480,7 +594,9 @@ int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t
     if (int rc = wait_published(h, c)) return rc;
     const int slot = (int)(c % kSlots);
     long long loc = h->host[slot].local, glob = h->host[slot].global;
-    if (h->mode == kModeShm) { int64_t total = 0; if (int rc = pulse_shm_all_sum(h->shm, c, loc, &total)) return rc; glob = total; }
+    if (h->global_known_idx[slot] == c) glob = h->global_known[slot];       // summed before (a paired launch's verdict)
+    else if (h->mode == kModeShm) { int64_t total = 0; if (int rc = pulse_shm_all_sum(h->shm, c, loc, &total)) return rc; glob = total; }
+    h->global_known[slot] = glob; h->global_known_idx[slot] = c;
     *local = loc; *global = glob; *have = 1;
     return 0;
 }

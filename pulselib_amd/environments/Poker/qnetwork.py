@@ -11,7 +11,8 @@ What is native here:
     indexing costs a device->host sync per mask);
   * `train_step_masked`: the same sync-free contract on PyTorch-ROCm autograd (every row goes through with a 0/1
     weight), kept as the torch cross-check of the native path.
-`train_step` itself keeps the reference's filtering semantics verbatim (Player.py:255-294) on PyTorch autograd."""
+`train_step` (the reference's signature) runs on the native kernels too; `train_step_torch` keeps the reference's
+filtering semantics and op sequence verbatim (Player.py:255-294) on PyTorch autograd."""
 from __future__ import annotations
 
 import copy
@@ -65,6 +66,7 @@ class PokerQNetwork(nn.Module):
         self.criterion = nn.MSELoss()
         self.to(device)
         self._native = None
+        self._flat = self._flat_target = None
         if torch.device(device).type == "cuda":
             self._flatten()                   # parameters become views of one flat buffer per network (pulse_env.h: PulseQNetTrain)
         self.optimizer = self.configure_optimizers()
@@ -74,6 +76,9 @@ class PokerQNetwork(nn.Module):
         self._struct_cache = {}
         self._lr_gate = None
         self.data_parallel = True            # under torch.distributed with > 1 rank: all-reduce the gradient every step
+        # the reduce launch applies AdamW itself behind a meeting of its workgroups (qnet.hip); True = AdamW as its own launch
+        self.separate_apply = False
+        self.meet_wait_ticks = 0             # 0: the library's 5 s (ticks of the 100 MHz clock)
 
     # ------------------------------------------------------------------ torch side
     def forward(self, states):
@@ -211,6 +216,7 @@ class PokerQNetwork(nn.Module):
         if t is not None and t.params == self._flat.data_ptr():
             t.lr, t.weight_decay, t.gamma, t.update_freq = self.lr, self.wd, float(self.gamma), int(self.update_freq)
             t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
+            t.separate_apply, t.meet_wait_ticks = int(self.separate_apply), int(self.meet_wait_ticks)
             return t
         t = self._struct_cache["train"] = _native.QNetTrain()
         t.net, t.target = self._net_struct(self.network), self._net_struct(self.target_network)
@@ -223,6 +229,7 @@ class PokerQNetwork(nn.Module):
         t.max_grad_norm, t.gamma = 1.0, float(self.gamma)                                      # clip_grad_norm_ (:280)
         t.dropout_p = float(self.network[4].p) if self.network.training else 0.0
         t.update_freq = int(self.update_freq)
+        t.separate_apply, t.meet_wait_ticks, t.debug_meet_extra = int(self.separate_apply), int(self.meet_wait_ticks), 0
         return t
 
     def train_step_native(self, states, actions, rewards, next_states, dones, row_mask=None, step_counter=None, terminated=None,
@@ -306,7 +313,33 @@ class PokerQNetwork(nn.Module):
             self.target_network.load_state_dict(self.network.state_dict())
 
     def train_step(self, states, actions, rewards, next_states, dones):
-        """Player.py:255-294, the reference's filtering semantics (boolean indexing: syncs with the host)."""
+        """Player.py:255-294 -- the reference's signature.  On the GPU the update runs on the native kernels
+        (`train_step_native` with every passed row a candidate; the filter on the seat status, :261, is the kernel's):
+        no boolean indexing, no `.any()` sync, no autograd graph.  Returns the MSE loss as a 0-d DEVICE tensor
+        (`float(loss)` works and only then waits for the GPU; 0 when no row was valid, as the reference's early return).
+        Moments and step count of this path live in its own buffers (`train_step_native`), not in `self.optimizer`;
+        dropout draws are Philox (a documented deviation).  `train_step_torch` is the same update on PyTorch autograd
+        with the reference's own op sequence -- what the reference-fixture test compares (and the path of a CPU module)."""
+        if self._flat is None or not (torch.is_tensor(states) and states.is_cuda):
+            return self.train_step_torch(states, actions, rewards, next_states, dones)
+        report = self.train_step_native(states, actions, rewards, next_states, dones, None)
+        if self.step_count % 1000 == 0:                                            # Player.py:281-287 (the Q / reward means are not kept)
+            print(f"Step {self.step_count} | Avg Loss: {float(report[1]):.2f} | Epsilon: {self.epsilon:.4f}")
+        return report[1]
+
+    def check_native_report(self, report_host=None):
+        """Raises if the last native update was called off inside its launch (report[3] = -1, pulse_env.h: PulseQNetTrain).
+        Reading the report waits for the stream; the trainer calls this at its per-episode read-back."""
+        if self._native is None:
+            return
+        rep = self._native["report"].cpu() if report_host is None else report_host
+        if float(rep[3]) < 0.0:
+            raise RuntimeError("PokerQNetwork: a reduce + AdamW launch could not gather its workgroups (is another process using this GPU?) "
+                               "and applied no update; set `separate_apply = True` to run AdamW as a launch of its own")
+
+    def train_step_torch(self, states, actions, rewards, next_states, dones):
+        """Player.py:255-294 with the reference's filtering semantics and op sequence on PyTorch autograd (boolean indexing:
+        syncs with the host)."""
         valid_mask = (states[:, 12] == 0) | (states[:, 12] == 2)                   # seat status ACTIVE or ALLIN (:261)
         if not valid_mask.any():
             return 0.0

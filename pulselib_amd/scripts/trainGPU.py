@@ -192,11 +192,13 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         stats.set(terminated.sum(), episode_reward, (final_stacks - initial_stacks).sum())
         totals = (stats.all_reduce_async() if reduce_stats else stats).wait()
         host = totals.cpu()                                                           # one read-back per episode
+        if native:
+            q_agent.check_native_report()                                             # an update called off inside its launch must not pass silently
         reward_scores.append(float(host[1]))
         scores.append(float(host[2]))
         if hand_metrics is not None:
             episode_metrics.append(hand_metrics.end_episode())
-        total_steps += n_games * idx                                                  # :108
+        total_steps += done_count.n_global * idx                                      # :108 (the tables of the whole job: every rank steps in lock step)
 
     torch.cuda.synchronize(device)
     done_count.close()

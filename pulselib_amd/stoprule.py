@@ -266,6 +266,25 @@ class LaggedDoneCount:
     def side_stream_check_points(self) -> int:
         return int(self._lib.pulse_stoprule_side_launches(self.handle)) if self.handle is not None else 0
 
+    OPT_VERDICT_WAIT_TICKS, OPT_ALLOW_SHARED_DEVICE_PAIRS, OPT_DEBUG_LATE_VERDICTS = 0, 1, 2     # pulse_env.h: PULSE_STOPRULE_OPT_*
+
+    def set_option(self, option: int, value: int) -> None:
+        """Options of the native handle (pulse_stoprule_set_option): how long a paired launch waits for its verdict, whether
+        ranks sharing a device may pair, the late-verdict test hook."""
+        if self.handle is None:
+            raise RuntimeError("set_option: no native handle (host-side count backend)")
+        _native.check(self._lib.pulse_stoprule_set_option(self.handle, int(option), int(value)), "pulse_stoprule_set_option")
+
+    def stats(self) -> dict:
+        """{'paired_launches': issued so far, 'verdict_timeouts': launches that gave up waiting for this host (each made
+        the handle fall back to one check interval per launch), 'pairs': whether the handle would still pair,
+        'side_stream_check_points'} -- bench.py reports the first three."""
+        if self.handle is None:
+            return {"paired_launches": 0, "verdict_timeouts": 0, "pairs": False, "side_stream_check_points": 0}
+        out = (C.c_int64 * 4)()
+        _native.check(self._lib.pulse_stoprule_stats(self.handle, out), "pulse_stoprule_stats")
+        return {"paired_launches": int(out[0]), "verdict_timeouts": int(out[1]), "pairs": bool(out[2]), "side_stream_check_points": int(out[3])}
+
     def drain(self) -> None:
         """Episode boundary: the chunks submitted so far decide nothing any more."""
         if self.backend is not None:

@@ -308,6 +308,43 @@ def test_shared_table_combines_simultaneous_updates_of_one_entry():
     assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) == 0 and int(agent._scratch_tensors["acc_cnt"].sum()) == 0      # scratch left clean
 
 
+def test_a_called_off_follow_up_launch_drops_its_updates_as_a_whole_and_fails_the_next_call():
+    """The follow-up launch that combines a LONG list of deferred updates spreads it over 64 workgroups that meet at a
+    counter (csrc/qtable.hip).  With the wait cut to 30 ms and one arrival more expected than the grid has (test hook)
+    the launch returns, NO combined update was applied (only the one compare-and-swap winner's own), the next call on
+    the table fails with PULSE_EINTERNAL once and clears the accumulators, and the table works again afterwards."""
+    import time
+    from pulselib_amd.agents import QLearningBatch
+    B, n = 4096, 4                                                 # 4,095 deferred transitions > 1,024: the spread form
+    dev = torch.device(DEV)
+    agent = QLearningBatch(dev, B, n, config={"ALPHA": 0.25, "GAMMA": 0.0, "EPSILON": 0.0}, slots=1 << 12, seed=1)
+    board = torch.tensor([[2, 4, 8, 16], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 2, 0]], dtype=torch.int32, device=dev)
+    boards = board.repeat(B, 1, 1).contiguous()
+    nxt = boards.clone(); nxt[:, 1, 1] = 2
+    rewards = torch.full((B,), 3, dtype=torch.int32, device=dev)
+    term = torch.zeros(B, dtype=torch.bool, device=dev)
+    agent._scratch.wait_ticks, agent._scratch.debug_meet_extra = 3_000_000, 1
+    acts = agent.get_actions(boards, 0)
+    a = int(acts[0])
+    t0 = time.perf_counter()
+    agent.update(nxt, rewards, term)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 2.0                          # 30 ms, not the default 3 s
+    tab = agent.table()
+    key = [k for k, v in tab.items() if v[a] != 0.0]
+    assert len(key) == 1 and abs(tab[key[0]][a] - 0.25 * 3.0) < 1e-12          # the winner's update alone: nothing half-combined
+    assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) > 0              # the accumulators stayed claimed ...
+    agent._scratch.debug_meet_extra = 0
+    with pytest.raises(RuntimeError, match="could not gather"):
+        agent.get_actions(boards, 1); agent.update(nxt, rewards, term)
+    torch.cuda.synchronize()
+    assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) == 0 and int(agent._scratch_tensors["acc_cnt"].sum()) == 0   # ... and are clean now
+    agent.get_actions(boards, 2)
+    agent.update(nxt, rewards, term)                               # an ordinary launch again: all B transitions land
+    q1 = 0.75 + (1.0 - 0.75 ** B) * (3.0 - 0.75)
+    assert abs(agent.table()[key[0]][a] - q1) < 1e-12
+
+
 def test_shared_q_table_learns_and_loses_no_update():
     """Shared-table mode at config-3 size: all 262,144 boards start from states with two tiles, so thousands of
     boards update the same entries concurrently; the CAS loop must apply every one of them."""

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(n_tables, table_id0, n_global, exchange, paired=True):
+def _run(n_tables, table_id0, n_global, exchange, paired=True, allow_shared=True):
     """EPISODES episodes of bench.EpisodeLoop; returns per-episode (steps, local done count) and the final state."""
     import bench
     from pulselib_amd.environments.Poker import PokerGPU
@@ -31,6 +31,10 @@ def _run(n_tables, table_id0, n_global, exchange, paired=True):
                    K=100, alpha=50, seed=bench.SEED, table_id0=table_id0)
     env.paired_launches = paired
     rule = LaggedDoneCount(dev, n_tables, bench.TERMINATION_THRESHOLD, lag=1, n_global=n_global, exchange=exchange)
+    if exchange == "shm" and allow_shared:
+        # both ranks sit on cuda:0: the rule would refuse to pair (their launches wait for hosts that wait for both launches to
+        # have started); two grids of 8,192 tables do fit the device together, so the test may lift that
+        rule.set_option(LaggedDoneCount.OPT_ALLOW_SHARED_DEVICE_PAIRS, 1)
     got = []
 
     def at_end(loop):
@@ -43,16 +47,17 @@ def _run(n_tables, table_id0, n_global, exchange, paired=True):
     torch.cuda.synchronize()
     state = {k: getattr(env, k).cpu().numpy().copy() for k in NAMES}
     mode = rule.native_mode
+    stats = rule.stats()
     rule.close()
-    return got[:EPISODES], state, mode
+    return got[:EPISODES], state, mode, stats
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, allow_shared):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out[rank] = _run(N_LOCAL, rank * N_LOCAL, world * N_LOCAL, "shm")
+        out[rank] = _run(N_LOCAL, rank * N_LOCAL, world * N_LOCAL, "shm", allow_shared=allow_shared)
     finally:
         dist.destroy_process_group()
 
@@ -60,14 +65,14 @@ def _worker(rank, world, port, out):
 def test_two_ranks_with_paired_launches_and_shm_exchange_equal_one_process():
     import torch.multiprocessing as mp
     world = 2
-    want, want_state, mode = _run(world * N_LOCAL, 0, world * N_LOCAL, None)
-    assert mode == "local"
-    unpaired, _, _ = _run(world * N_LOCAL, 0, world * N_LOCAL, None, paired=False)
-    assert unpaired == want                                                  # (and pairing itself changes nothing)
+    want, want_state, mode, st = _run(world * N_LOCAL, 0, world * N_LOCAL, None)
+    assert mode == "local" and st["paired_launches"] > 0
+    unpaired, _, _, st = _run(world * N_LOCAL, 0, world * N_LOCAL, None, paired=False)
+    assert unpaired == want and st["paired_launches"] == 0                   # (and pairing itself changes nothing)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert all(out[r][2] == "shm" for r in range(world))
+    mp.spawn(_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
+    assert all(out[r][2] == "shm" and out[r][3]["paired_launches"] > 0 and out[r][3]["verdict_timeouts"] == 0 for r in range(world))
     steps = [[e[0] for e in out[r][0]] for r in range(world)]
     assert steps[0] == steps[1] == [e[0] for e in want], (steps, want)        # every rank ends every episode where the whole job does
     for e in range(EPISODES):
@@ -77,3 +82,20 @@ def test_two_ranks_with_paired_launches_and_shm_exchange_equal_one_process():
             np.testing.assert_array_equal(out[r][1][k], want_state[k][r * N_LOCAL:(r + 1) * N_LOCAL], err_msg=f"rank {r} {k}")
     lengths = {e[0] for e in want}
     assert len(lengths) > 1 and min(lengths) < CAP, f"the rule must end some episodes before the cap (lengths {sorted(lengths)})"
+
+
+def test_ranks_that_share_a_device_do_not_pair_unless_told_to():
+    """The guard sits in the native rule, not in the bench: two ranks on ONE GPU (shm exchange, PCI bus ids in the segment)
+    run one check interval per launch -- no launch of theirs ever waits for a host -- and still play the single process's
+    episodes."""
+    import torch.multiprocessing as mp
+    world = 2
+    want, want_state, _, _ = _run(world * N_LOCAL, 0, world * N_LOCAL, None)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, False), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r][2] == "shm" and out[r][3]["paired_launches"] == 0 and not out[r][3]["pairs"], out[r][3]
+        assert [e[0] for e in out[r][0]] == [e[0] for e in want]
+        for k in NAMES:
+            np.testing.assert_array_equal(out[r][1][k], want_state[k][r * N_LOCAL:(r + 1) * N_LOCAL], err_msg=f"rank {r} {k}")

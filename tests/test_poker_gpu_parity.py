@@ -962,6 +962,144 @@ def test_paired_launches_run_the_episodes_of_one_chunk_per_launch(N):
     ra.close(); rb.close()
 
 
+@pytest.mark.parametrize("N,rank,world_tables", [(65536, 0, 65536), (131072, 3, 1048576)],
+                         ids=["65536-bench-kernel", "131072-config4-shard"])
+def test_paired_launches_match_the_oracle_after_every_launch(oracle_table, N, rank, world_tables):
+    """The launch the bench actually times -- `rollout_until` under the lag-1 rule, TWO check intervals per launch, the
+    launch taking the rule's verdicts itself -- held to the ORACLE directly (round 3 reached it only through aggregates
+    and through paired = unpaired): calls of at most 10 steps = one paired launch each; after every launch the whole
+    state, both observation / reward / done sets and the actions against OraclePokerEnv.policy_step taken step by step.
+    The rule's threshold is put between the oracle's done fractions of two check points so that the episode ends where
+    the test wants it: once behind an ODD check point (the next launch is cut to its first five steps by `stop_mid`)
+    and once behind an EVEN one (the next launch is enqueued and cancelled by `skip_all`: it must leave no trace).
+    (PokerGPU.py:527-633; scripts/Poker/trainGPU.py:27-33,79-99)"""
+    import bench
+    from oracle import oracle as orc
+    from pulselib_amd.stoprule import LaggedDoneCount
+    seed, t0 = 20260401, rank * N
+    dev = torch.device(DEV)
+    kw = dict(n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50)
+    env = _gpu_env(seed=seed, table_id0=t0, **kw)
+    assert env.chunked_rollout and env.paired_launches
+    ref = orc.OraclePokerEnv(hand_ranks_table=oracle_table, n_threads=16, **kw)
+    a_gpu = torch.zeros(N, dtype=torch.long, device=DEV)
+    a_ref = np.zeros(N, dtype=np.int64)
+    gstep, seen = 0, set()
+    for e, (A, ep_types, parity) in enumerate(((10, 0, 1), (6, 1, 0))):
+        native, q_seat, rotation = bench.native_types_for_episode(ep_types)
+        opts = {"rotation": rotation, "active_players": A, "q_agent_seat": q_seat}
+        env.reset(options=opts)
+        decks = to_np(env.decks)
+        np.testing.assert_array_equal(decks, orc.shuffle_decks(seed, t0, e, N), err_msg=f"episode {e}: device shuffle")
+        ref.reset(options=dict(opts, prefixed_decks=decks))
+        # the oracle's whole episode first: a record after every check interval
+        chunks, frac = [], []
+        for c in range(8):
+            for i in range(5):
+                if i == 4:
+                    before = (ref.obs.copy(), ref.rewards.copy(), ref.is_done.copy())
+                ref.policy_step(native, seed, gstep + 5 * c + i, a_ref, table_id0=t0)
+            chunks.append(dict(state=ref.snapshot(), rewards=ref.rewards.copy(), done=ref.is_done.copy(), before=before, actions=a_ref.copy(),
+                               prev_stacks=ref.prev_stacks.copy(), prev_invested=ref.prev_invested.copy()))
+            frac.append(float(ref.is_done.mean()))
+        cross = next(c for c in range(1, 6) if c % 2 == parity and frac[c] > frac[c - 1] + 4.0 / N)
+        rule = LaggedDoneCount(dev, N, 0.5 * (frac[cross - 1] + frac[cross]), lag=1)
+        n_chunks = cross + 2                                  # lag 1: the chunk after the crossing still runs, the one after that does not
+        done = 0
+        for call in range(8):
+            steps, over = env.rollout_until(native, a_gpu, 5, 10, gstep + 5 * done, rule)
+            left = n_chunks - done
+            # (a launch that runs both its chunks never ends the episode itself: `over` comes with the launch that is cut or cancelled)
+            want = (10, False) if left >= 2 else ((5, True) if left == 1 else (0, True))
+            assert (steps, over) == want, f"N={N} episode {e} call {call}: got {(steps, over)}, want {want} (crossing at check point {cross})"
+            if steps == 5:
+                seen.add("cut")
+            if steps == 0:
+                seen.add("cancelled")
+            done += steps // 5
+            ctx = f"N={N} episode {e} call {call} ({steps} steps, {done} chunks done)"
+            rec = chunks[done - 1]
+            got = _snap(env)
+            assert_state_equal(got, rec["state"], ctx=ctx)
+            np.testing.assert_array_equal(got["obs"], rec["state"]["obs"], err_msg=ctx + " obs")
+            np.testing.assert_array_equal(got["equities"], rec["state"]["equities"], err_msg=ctx + " equities")
+            np.testing.assert_array_equal(to_np(env.is_done).astype(np.uint8), rec["done"].astype(np.uint8), err_msg=ctx + " dones")
+            np.testing.assert_array_equal(to_np(a_gpu), rec["actions"], err_msg=ctx + " actions")
+            assert_rewards_close(env._rewards[1 - env._pp], rec["rewards"], 50, ctx + " rewards of the last step")
+            # the other set of the ping-pong pair: what the step before the last one stored
+            np.testing.assert_array_equal(to_np(env._obs_bufs[1 - env._pp]), rec["before"][0], err_msg=ctx + " observation of the step before")
+            assert_rewards_close(env._rewards[env._pp], rec["before"][1], 50, ctx + " rewards of the step before")
+            np.testing.assert_array_equal(to_np(env._done_bufs[1 - env._pp]).astype(np.uint8), rec["before"][2].astype(np.uint8), err_msg=ctx + " dones of the step before")
+            for name in ("prev_stacks", "prev_invested"):
+                np.testing.assert_array_equal(to_np(getattr(env, name)), rec[name], err_msg=f"{ctx} {name}")
+            if over:
+                break
+        assert over and done == n_chunks
+        assert rule.stats()["verdict_timeouts"] == 0 and rule.stats()["paired_launches"] >= 3
+        rule.close()
+        gstep += 40
+    assert seen == {"cut", "cancelled"}, seen
+
+
+def test_a_late_verdict_makes_the_launch_give_up_and_the_loop_fall_back():
+    """The paired launch is the one place where device code waits for the host.  With the wait cut to
+    50 ms and the host told to be "too late" for one verdict (test hook), that launch gives up -- returns within its wait,
+    stores nothing --, the native loop runs the same steps with one check interval per launch, the handle counts the
+    time-out and never pairs again: every episode, before and after, equals the loop that never paired, bit for bit."""
+    import time
+    from pulselib_amd.stoprule import LaggedDoneCount
+    dev = torch.device(DEV)
+    N = 8192
+    kw = dict(n_players=6, max_players=10, n_games=N, seed=33, table_id0=7)
+    a, b = _gpu_env(**kw), _gpu_env(**kw)
+    b.paired_launches = False
+    ra, rb = LaggedDoneCount(dev, N, 0.8, lag=1), LaggedDoneCount(dev, N, 0.8, lag=1)
+    ra.set_option(LaggedDoneCount.OPT_VERDICT_WAIT_TICKS, 5_000_000)
+    types = [1, 3, 2, 4, 5, 1]
+    acts = [torch.zeros(N, dtype=torch.long, device=dev) for _ in range(2)]
+    gstep = 0
+    for e, caps in enumerate(((60,), (10, 40), (60,), (13, 40))):      # (after 10 steps no verdict is due yet: episode 1 has a second call)
+        A = (6, 5, 4, 6)[e]
+        for env, rule in ((a, ra), (b, rb)):
+            env.reset(options={"active_players": A, "rotation": e})
+            rule.drain()
+        total = 0
+        for ci, cap in enumerate(caps):
+            if e == 1 and ci == 1:                         # mid-episode: the second launch of this episode finds its host "late"
+                assert ra.stats() == dict(ra.stats(), verdict_timeouts=0, pairs=True)
+                ra.set_option(LaggedDoneCount.OPT_DEBUG_LATE_VERDICTS, 1)
+            t0 = time.perf_counter()
+            got = a.rollout_until(types, acts[0], 5, cap, gstep + total, ra)
+            torch.cuda.synchronize()
+            assert time.perf_counter() - t0 < 5.0
+            want = b.rollout_until(types, acts[1], 5, cap, gstep + total, rb)
+            assert got == want, f"episode {e} cap {cap}: {got} vs unpaired {want}"
+            total += got[0]
+            for name in ROLLOUT_MEMORY:
+                np.testing.assert_array_equal(to_np(getattr(a, name)), to_np(getattr(b, name)), err_msg=f"episode {e} cap {cap} {name}")
+            for k in range(2):
+                np.testing.assert_array_equal(to_np(a._obs_bufs[k]), to_np(b._obs_bufs[k]), err_msg=f"episode {e} obs buffer {k}")
+                np.testing.assert_array_equal(to_np(a._rewards[k]), to_np(b._rewards[k]), err_msg=f"episode {e} rewards buffer {k}")
+                np.testing.assert_array_equal(to_np(a._done_bufs[k]), to_np(b._done_bufs[k]), err_msg=f"episode {e} done buffer {k}")
+            assert a._pp == b._pp
+            np.testing.assert_array_equal(to_np(acts[0]), to_np(acts[1]))
+            if got[1]:
+                break
+        gstep += total
+        st = ra.stats()
+        if e == 0:
+            assert st["verdict_timeouts"] == 0 and st["pairs"] and st["paired_launches"] > 0
+            paired_before = st["paired_launches"]
+        if e >= 1:
+            assert st["verdict_timeouts"] == 1 and not st["pairs"]
+        if e == 1:
+            paired_at_timeout = st["paired_launches"]
+            assert paired_at_timeout > paired_before
+        if e > 1:
+            assert st["paired_launches"] == paired_at_timeout         # one check interval per launch from the time-out on
+    ra.close(); rb.close()
+
+
 def test_rccl_exchange_with_one_rank_decides_like_the_local_rule():
     """exchange="rccl": the stop rule's count goes through a NATIVE RCCL communicator (librccl bound with dlopen,
     csrc/stoprule.hip) -- one int64 all-reduce per check point on the rule's side stream, handed over by events.  One

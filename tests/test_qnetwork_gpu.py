@@ -150,8 +150,8 @@ def test_train_step_masked_equals_filtered_train_step(g):
     t = {k: torch.from_numpy(g[f"s40/{k}"]).to(DEV) for k in ("states", "next_states", "actions", "rewards", "dones")}
     row_mask = torch.arange(t["states"].shape[0], device=DEV) % 2 == 0
     for _ in range(3):
-        la = qa.train_step(states=t["states"][row_mask], actions=t["actions"][row_mask], rewards=t["rewards"][row_mask],
-                           next_states=t["next_states"][row_mask], dones=t["dones"][row_mask])
+        la = qa.train_step_torch(states=t["states"][row_mask], actions=t["actions"][row_mask], rewards=t["rewards"][row_mask],
+                                 next_states=t["next_states"][row_mask], dones=t["dones"][row_mask])
         lb = qb.train_step_masked(t["states"], t["actions"], t["rewards"], t["next_states"], t["dones"], row_mask)
         assert abs(float(la) - float(lb)) < 1e-4 * max(1.0, abs(float(la)))
     for (k, va), vb in zip(qa.network.state_dict().items(), qb.network.state_dict().values()):
@@ -297,6 +297,84 @@ def test_native_gradient_matches_oracle_and_torch_autograd(g):
                          for i in LINEARS])
     np.testing.assert_allclose(mean_grad, tg, rtol=0, atol=GRAD_RTOL * np.abs(tg).max())
     assert abs(float(loss) - rep[1]) < 1e-4 * max(1.0, float(loss))
+
+
+def test_reference_signature_train_step_runs_the_native_kernels(g):
+    """PokerQNetwork.train_step(states, actions, rewards, next_states, dones) (Player.py:255-294) on a GPU module IS the
+    native update: same parameters as train_step_native with no row mask, within the native tolerance of the torch
+    reference path (dropout off), loss returned as a 0-d device tensor, no-valid-row batch = no-op returning 0."""
+    qa, qb, qc = _qnet(g, "s40", seed=9), _qnet(g, "s40", seed=9), _qnet(g, "s40", seed=9)
+    for q in (qa, qb, qc):
+        q.network.eval()
+    b = _batch(2000, 21)
+    dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
+    for it in range(2):
+        la = qa.train_step(states=dev["states"], actions=dev["actions"], rewards=dev["rewards"], next_states=dev["next_states"], dones=dev["dones"])
+        assert isinstance(la, torch.Tensor) and la.is_cuda and la.dim() == 0
+        la = float(la)                                              # (the tensor is a view of the report: read it before the next step)
+        rep = qb.train_step_native(dev["states"], dev["actions"], dev["rewards"], dev["next_states"], dev["dones"], None,
+                                   step_counter=(1 << 41) + it + 1)
+        lc = qc.train_step_torch(states=dev["states"], actions=dev["actions"], rewards=dev["rewards"], next_states=dev["next_states"], dones=dev["dones"])
+        assert la == float(rep[1])
+        assert abs(la - float(lc)) < 1e-4 * max(1.0, abs(float(lc)))
+    np.testing.assert_array_equal(_flat(qa.network), _flat(qb.network))
+    np.testing.assert_allclose(_flat(qa.network), _flat(qc.network), rtol=0, atol=PARAM_ATOL)
+    assert qa.step_count == 2 and qa.native_steps() == 2
+    before = _flat(qa.network)
+    dead = dev["states"].clone(); dead[:, 12] = 1                 # every seat folded: nothing valid (:261-262)
+    assert float(qa.train_step(dead, dev["actions"], dev["rewards"], dev["next_states"], dev["dones"])) == 0.0
+    np.testing.assert_array_equal(_flat(qa.network), before)
+
+
+def test_a_called_off_meeting_updates_nothing_and_fails_the_next_call(g):
+    """The reduce + AdamW launch is a meeting of its workgroups (qnet.hip).  With the wait cut to 50 ms and one arrival
+    more expected than the grid has (the test hook: the meeting cannot come about) the launch returns, no parameter,
+    moment or step count has moved, report[3] = -1, the learner's report check raises and the next native call fails
+    with PULSE_EINTERNAL -- once; training then goes on (the meeting is all or nothing: a counter that is short is
+    marked with a compare-and-swap, so no workgroup can apply its part while another skips its own)."""
+    import time
+    from pulselib_amd import _native
+    q = _qnet(g, "s40", seed=4)
+    b = _batch(3000, 5)
+    dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
+    args = (dev["states"], dev["actions"], dev["rewards"], dev["next_states"], dev["dones"], dev["row_mask"])
+    q.train_step_native(*args)                                      # one ordinary step: moments are non-zero from here
+    torch.cuda.synchronize()
+    p0, m0, v0, s0 = _flat(q.network), q._native["m"].clone(), q._native["v"].clone(), q.native_steps()
+    t = q._native_state(3000)
+    q.meet_wait_ticks = 5_000_000                                   # 50 ms of the 100 MHz clock
+    t.debug_meet_extra = 1
+    t.meet_wait_ticks = q.meet_wait_ticks
+    t0 = time.perf_counter()
+    rep = q.train_step_native(*args).cpu().numpy().copy()
+    assert time.perf_counter() - t0 < 5.0                           # it gave up after its 50 ms, not after the default 5 s
+    assert rep[3] == -1.0 and rep[0] == 0.0
+    np.testing.assert_array_equal(_flat(q.network), p0)
+    assert torch.equal(q._native["m"], m0) and torch.equal(q._native["v"], v0) and q.native_steps() == s0
+    with pytest.raises(RuntimeError, match="applied no update"):
+        q.check_native_report()
+    t.debug_meet_extra = 0
+    with pytest.raises(RuntimeError, match="PULSE_EINTERNAL|could not gather"):
+        q.train_step_native(*args)
+    rep = q.train_step_native(*args).cpu().numpy()                  # reported once; the next step is an ordinary one
+    assert rep[3] == 0.0 and rep[0] > 0 and q.native_steps() == s0 + 1
+    q.check_native_report()
+    assert np.abs(_flat(q.network) - p0).max() > 0
+
+
+def test_separate_apply_equals_the_in_launch_adamw(g):
+    """`separate_apply` (AdamW as a launch of its own: what a device that cannot hold the reduce grid at once gets, and
+    what the data-parallel path always runs) gives the parameters of the in-launch form."""
+    qa, qb = _qnet(g, "s40", seed=6), _qnet(g, "s40", seed=6)
+    qb.separate_apply = True
+    for it in range(3):
+        b = _batch(4000, 300 + it)
+        dev = {k: torch.from_numpy(x).to(DEV) for k, x in b.items()}
+        ra = qa.train_step_native(dev["states"], dev["actions"], dev["rewards"], dev["next_states"], dev["dones"], dev["row_mask"], step_counter=it).cpu().numpy().copy()
+        rb = qb.train_step_native(dev["states"], dev["actions"], dev["rewards"], dev["next_states"], dev["dones"], dev["row_mask"], step_counter=it).cpu().numpy().copy()
+        assert ra[0] == rb[0] and abs(ra[1] - rb[1]) <= 1e-6 * max(1.0, abs(ra[1]))
+        np.testing.assert_allclose(_flat(qa.network), _flat(qb.network), rtol=0, atol=PARAM_ATOL)
+    assert qa.native_steps() == qb.native_steps() == 3
 
 
 def test_native_training_reduces_td_error_on_a_fixed_batch(g):

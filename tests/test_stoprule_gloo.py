@@ -164,3 +164,49 @@ def test_trainer_cadence_breaks_at_the_same_step_on_both_ranks():
     assert out[0] == out[1] and all(0 < e < 60 for e in out[0])
     # mean rate 0.07 per step: > 0.8 from idx 11 on -> first check that sees it is idx 15, its verdict comes at idx 20
     assert out[0] == [20, 20, 20, 20]
+
+
+def test_shm_segment_tells_ranks_that_share_a_device():
+    """The shared-memory exchange carries the GPU each rank computes on (pulse_shm_set_device: the PCI bus id).  Ranks whose
+    device is also another rank's must not use launches that wait for each other's hosts (csrc/stoprule.hip:
+    stoprule_pairs_supported): device_is_private answers 0 for them, 0 for a rank that has not named its device and while
+    another rank has not (bounded wait), 1 once every rank has named a device of its own."""
+    import ctypes as C
+    from pulselib_amd import _native
+    lib = _native.lib()
+    name = f"/pulse_test_devices_{os.getpid()}".encode()
+    try:
+        os.unlink("/dev/shm" + name.decode())
+    except OSError:
+        pass
+    hs = []
+    for r in range(3):
+        h = C.c_void_p()
+        _native.check(lib.pulse_shm_create(name, r, 3, C.byref(h)), "pulse_shm_create")
+        hs.append(h)
+    os.unlink("/dev/shm" + name.decode())
+    try:
+        assert lib.pulse_shm_device_is_private(hs[0], 10) == 0            # has not named its own device yet
+        _native.check(lib.pulse_shm_set_device(hs[0], b"0000:05:00.0"), "pulse_shm_set_device")
+        assert lib.pulse_shm_device_is_private(hs[0], 10) == 0            # ranks 1, 2 still unknown: treated as shared
+        _native.check(lib.pulse_shm_set_device(hs[1], b"0000:26:00.0"), "pulse_shm_set_device")
+        _native.check(lib.pulse_shm_set_device(hs[2], b"0000:05:00.0"), "pulse_shm_set_device")
+        assert lib.pulse_shm_device_is_private(hs[1], 10) == 1            # nobody else on 26:00.0
+        assert lib.pulse_shm_device_is_private(hs[0], 10) == 0 and lib.pulse_shm_device_is_private(hs[2], 10) == 0   # ranks 0 and 2 share 05:00.0
+        _native.check(lib.pulse_shm_set_device(hs[2], b"0000:45:00.0"), "pulse_shm_set_device")
+        assert [lib.pulse_shm_device_is_private(h, 10) for h in hs] == [1, 1, 1]
+        # the sums still work beside the device records
+        total = C.c_int64(0)
+        import threading
+        out = [0, 0, 0]
+
+        def rank(r):
+            t = C.c_int64(0)
+            _native.check(lib.pulse_shm_all_sum(hs[r], 0, 10 ** r, C.byref(t)), "pulse_shm_all_sum")
+            out[r] = t.value
+        ts = [threading.Thread(target=rank, args=(r,)) for r in range(3)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert out == [111, 111, 111]
+    finally:
+        for h in hs:
+            lib.pulse_shm_destroy(h)

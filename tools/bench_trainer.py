@@ -60,13 +60,12 @@ def main():
     out = run(env, agents, types, args.episodes, args.tables, device, **kw)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    steps = out["total_steps"] // args.tables
+    steps = out["total_steps"] // (args.tables * world)       # (train_agent_fused counts the tables of the whole job)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        out["total_steps"] *= world
     if rank == 0:
         print(json.dumps({"metric": "trainer-loop env-steps/sec, Poker batched tables (learner acting and learning every step)",
                       "value": out["total_steps"] / elapsed, "unit": "env-steps/sec", "n_gpus": world, "loop": args.loop, "learner": args.learner if args.loop == "fused" else "torch",
