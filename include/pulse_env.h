@@ -327,7 +327,11 @@ int pulse_blackjack_reset(const PulseBlackjackView* v, const int32_t* decks_src,
                           uint64_t seed, uint64_t episode, void* stream);
 int pulse_blackjack_step(const PulseBlackjackView* v, const int64_t* actions, void* stream);   /* :113-186 */
 
-/* ---- 2048 (environments/2048/TFE.py), batched: boards device int32[B,n,n] ---------------------- */
+/* ---- 2048 (environments/2048/TFE.py), batched: boards device int32[B,n,n], n = 2..8 ------------
+ * 4 x 4 (config/tfe.yaml) with 16-byte aligned boards runs packed: the board as 64 bits of 4-bit log2 tiles, the move as four
+ * lookups in a 65,536-entry row table the library builds on the device at the first call (256 KB of static device memory, one
+ * synchronisation of the null stream, once per device); a board holding anything but 0 and the powers of two 2 .. 16,384 is
+ * stepped cell by cell like the other sides -- any int32 board gives the reference's result. */
 int pulse_tfe_reset(int32_t* boards, int64_t* total_score, int32_t n_boards, int32_t n, uint64_t seed,
                     uint64_t board_id0, void* stream);                                          /* :143-149 */
 int pulse_tfe_step(int32_t* boards, int64_t* total_score, const int64_t* actions, int32_t* rewards,

@@ -12,6 +12,8 @@
 // state word; no LDS, no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "pulse_internal.h"
 #include "tfe_device.h"
 
@@ -27,8 +29,9 @@ __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per word pair (v_mad_u64_u32): 32-bit integer multiplies are the slow vector instructions here
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -143,6 +146,98 @@ __global__ __launch_bounds__(kBlock) void blackjack_step_kernel(const PulseBlack
 
 // ------------------------------------------------------------------------------------ 2048
 // (the move itself: tfe_device.h)
+
+// The row table of the packed 4 x 4 move (tfe_device.h): 65,536 entries, built on the device once per device.
+__device__ uint32_t g_tfe_row_lut[65536];
+__global__ __launch_bounds__(kBlock) void tfe_row_lut_kernel() {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    g_tfe_row_lut[r] = tfe_row_lut_entry(r);
+}
+
+// 4 x 4 boards, one lane per board.  The wavefront's 64 boards are one contiguous 4 KB block: it is loaded as four fully
+// coalesced 16-byte-per-lane instructions (lane i of load j holds ROW (64 j + i) mod 4 of board (64 j + i) / 4 -- whose board
+// that is does not matter to the encoding, which is cell by cell), every row is packed to 16 bits of 4-bit log2 tiles
+// (tfe_device.h) and dropped into the wavefront's 512 bytes of LDS, from which each lane reads its own board as one 64-bit
+// word; the move is four row-table lookups, spawn and game-over test run on the packed word, and the way out is the way in
+// reversed.  (A lane loading its own 64 bytes touches four lines per instruction with sixteen bytes each.)  343 vector
+// instructions per wavefront against the cell form's 1,430 (below: still the path of other board sides, of resets, and of a
+// wavefront that meets a board the packed form cannot hold or that is the ragged last one).
+__global__ __launch_bounds__(kBlock) void tfe_step4_kernel(int32_t* __restrict__ boards, int64_t* __restrict__ total_score,
+                                                          const int64_t* __restrict__ actions, int32_t* __restrict__ rewards,
+                                                          uint8_t* __restrict__ dones, int n_boards, uint64_t seed,
+                                                          uint64_t board_id0, uint64_t step_counter, const uint32_t* __restrict__ lut) {
+    __shared__ alignas(16) uint16_t rows_lds[kBlock / 64][256];
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, g0 = g - lane;
+    if (g0 >= n_boards) return;
+    const bool whole = g0 + 64 <= n_boards;                                            // (wavefront-uniform)
+    uint16_t* mine = rows_lds[threadIdx.x >> 6];
+    int4* blk = reinterpret_cast<int4*>(boards + (size_t)g0 * 16);
+    int4 in[4];
+    int64_t ts = 0; int k = 0;
+    if (whole) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in[j] = blk[64 * j + lane];
+        ts = total_score[g];
+        k = (int)(actions[g] & 3);                                                      // TFE.py:154
+    }
+    __builtin_amdgcn_sched_barrier(0);                                                  // every load is in flight before anything waits
+    bool fast = whole;
+    PackedBoard pb{0u, 0u};
+    if (whole) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c[4] = {(uint32_t)in[j].x, (uint32_t)in[j].y, (uint32_t)in[j].z, (uint32_t)in[j].w};
+            uint32_t row = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bad |= (c[q] & (c[q] - 1u)) | (c[q] & 0xFFFF8001u);                   // anything but 0 and 2^1 .. 2^14 (tfe_pack4)
+                row |= (31u - (uint32_t)__clz((int)(c[q] | 1u))) << (4 * q);
+            }
+            mine[64 * j + lane] = (uint16_t)row;
+        }
+        fast = !__any(bad != 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fast) {
+            const uint2 w = *reinterpret_cast<const uint2*>(mine + 4 * lane);           // (a wavefront's LDS operations retire in order)
+            pb.lo = w.x; pb.hi = w.y;
+        }
+    }
+    if (fast) {
+        const U4 rnd = philox4x32(seed, board_id0 + (uint64_t)g, step_counter);
+        const int score = tfe_move_packed(pb, k, lut);
+        const int empty_before = tfe_spawn_packed(pb, rnd.x, rnd.y);                   // TFE.py:182 (always)
+        const bool over = tfe_over_packed(pb, empty_before);                           // TFE.py:48-67
+        *reinterpret_cast<uint2*>(mine + 4 * lane) = make_uint2(pb.lo, pb.hi);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        total_score[g] = ts + score;                                                    // TFE.py:168
+        rewards[g] = score > 0 ? 31 - __clz(score) : 0;                                 // TFE.py:185-187
+        dones[g] = over;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t row = mine[64 * j + lane];
+            blk[64 * j + lane] = make_int4((int)((1u << (row & 15u)) & ~1u), (int)((1u << ((row >> 4) & 15u)) & ~1u),
+                                           (int)((1u << ((row >> 8) & 15u)) & ~1u), (int)((1u << (row >> 12)) & ~1u));
+        }
+        return;
+    }
+    // the cell form: this lane's own board
+    if (g >= n_boards) return;
+    int b[16];
+    int4* p4 = reinterpret_cast<int4*>(boards + (size_t)g * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int4 x = p4[q]; b[4 * q] = x.x; b[4 * q + 1] = x.y; b[4 * q + 2] = x.z; b[4 * q + 3] = x.w; }
+    const U4 rnd = philox4x32(seed, board_id0 + (uint64_t)g, step_counter);
+    const int score = tfe_move<4>(b, (int)(actions[g] & 3));
+    tfe_spawn<4>(b, rnd.x, rnd.y);
+    total_score[g] += score;
+    rewards[g] = score > 0 ? 31 - __clz(score) : 0;
+    dones[g] = tfe_over<4>(b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p4[q] = make_int4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+}
+
 template <int NB>
 __global__ __launch_bounds__(kBlock) void tfe_step_kernel(int32_t* __restrict__ boards, int64_t* __restrict__ total_score,
                                                          const int64_t* __restrict__ actions, int32_t* __restrict__ rewards,
@@ -186,6 +281,65 @@ __global__ __launch_bounds__(kBlock) void tfe_step_kernel(int32_t* __restrict__ 
     }
 }
 
+// Any board side from 2 to 8 (the reference takes any board_height, TFE.py:112-131; the sides it is run at have the kernels
+// above): one lane per board, the board in a per-lane array addressed at run time -- the reference's loops as they stand.
+constexpr int kTfeAnyMax = 8;
+__global__ __launch_bounds__(kBlock) void tfe_step_any_kernel(int32_t* __restrict__ boards, int64_t* __restrict__ total_score,
+                                                             const int64_t* __restrict__ actions, int32_t* __restrict__ rewards,
+                                                             uint8_t* __restrict__ dones, int n_boards, int n, uint64_t seed,
+                                                             uint64_t board_id0, uint64_t step_counter, int is_reset) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n_boards) return;
+    int x[kTfeAnyMax * kTfeAnyMax];
+    const int cells = n * n;
+    int32_t* bp = boards + (size_t)g * cells;
+    const U4 rnd = philox4x32(seed, board_id0 + (uint64_t)g, step_counter);
+    auto spawn = [&](uint32_t r_cell, uint32_t r_val) {                                 // TFE.py:17-34
+        int ne = 0;
+        for (int i = 0; i < cells; ++i) ne += x[i] == 0;
+        if (!ne) return;
+        const int kth = (int)__umulhi(r_cell, (uint32_t)ne);
+        const int val = (float)(r_val >> 8) * (1.0f / 16777216.0f) > 0.9f ? 4 : 2;
+        int seen = 0;
+        for (int i = 0; i < cells; ++i) if (x[i] == 0) { if (seen == kth) x[i] = val; ++seen; }
+    };
+    int score = 0;
+    if (is_reset) {                                                                     // TFE.py:143-149
+        for (int i = 0; i < cells; ++i) x[i] = 0;
+        spawn(rnd.x, rnd.y); spawn(rnd.z, rnd.w);
+        total_score[g] = 0;
+    } else {
+        for (int i = 0; i < cells; ++i) x[i] = bp[i];
+        const int k = (int)(actions[g] & 3);                                            // TFE.py:154
+        for (int r = 0; r < n; ++r) {                                                   // row r of the board rotated k times (TFE.py:38-44, 158-178)
+            int at[kTfeAnyMax], res[kTfeAnyMax];
+            for (int c = 0; c < n; ++c) {
+                int rr = r, cc = c;
+                for (int q = 0; q < k; ++q) { const int nr = cc, nc = n - 1 - rr; rr = nr; cc = nc; }
+                at[c] = rr * n + cc; res[c] = 0;
+            }
+            int w = 0; bool last_merged = false;
+            for (int c = 0; c < n; ++c) {                                               // TFE.py:85-101
+                const int val = x[at[c]];
+                if (val == 0) continue;
+                if (res[w] == 0) res[w] = val;
+                else if (res[w] == val && !last_merged) { res[w] = val * 2; score += val * 2; last_merged = true; }
+                else { w += 1; res[w] = val; last_merged = false; }
+            }
+            for (int c = 0; c < n; ++c) x[at[c]] = res[c];
+        }
+        total_score[g] += score;                                                        // TFE.py:168
+        spawn(rnd.x, rnd.y);                                                            // TFE.py:182 (always)
+        rewards[g] = score > 0 ? 31 - __clz(score) : 0;                                 // TFE.py:185-187
+        bool over = true;                                                               // TFE.py:48-67
+        for (int i = 0; i < cells; ++i) over = over && x[i] != 0;
+        for (int r = 0; r < n; ++r) for (int c = 0; c + 1 < n; ++c) over = over && x[r * n + c] != x[r * n + c + 1];
+        for (int r = 0; r + 1 < n; ++r) for (int c = 0; c < n; ++c) over = over && x[r * n + c] != x[(r + 1) * n + c];
+        dones[g] = over;
+    }
+    for (int i = 0; i < cells; ++i) bp[i] = x[i];
+}
+
 // ------------------------------------------------------------------------------------ Particle2D
 __global__ __launch_bounds__(kBlock) void particle2d_step_kernel(float4* __restrict__ state, const float2* __restrict__ action,
                                                                 int32_t* __restrict__ steps, float4* __restrict__ obs_out,
@@ -225,6 +379,31 @@ int check_bj(const PulseBlackjackView* v) {
 
 }  // namespace
 
+namespace pulse {
+// The current device's row table of the packed 2048 move (tfe_device.h), built at the first call on that device (a launch
+// of 256 workgroups + one synchronisation, once).  qtable.hip's fused roll-out step uses it too.
+int tfe_row_lut(const uint32_t** out) {
+    static const uint32_t* table[64] = {nullptr};
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) return fail_hip((int)e, "pulse_tfe: hipGetDevice");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!table[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_tfe_row_lut));
+        if (e != hipSuccess) return fail_hip((int)e, "pulse_tfe: row table symbol");
+        hipLaunchKernelGGL(tfe_row_lut_kernel, dim3(65536 / kBlock), dim3(kBlock), 0, (hipStream_t)0);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0);
+        if (e != hipSuccess) return fail_hip((int)e, "pulse_tfe: row table build");
+        table[dev] = static_cast<const uint32_t*>(p);
+    }
+    *out = table[dev];
+    return 0;
+}
+}  // namespace pulse
+
 extern "C" {
 
 int pulse_blackjack_reset(const PulseBlackjackView* v, const int32_t* decks_src, int32_t* decks_out, uint64_t seed,
@@ -252,11 +431,20 @@ static int tfe_launch(int32_t* boards, int64_t* total_score, const int64_t* acti
     if (!is_reset && (!actions || !rewards || !dones)) return pulse::fail(PULSE_EINVAL, "pulse_tfe_step: null argument");
     if (n_boards == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (n == 4 && !is_reset && ((uintptr_t)boards & 15u) == 0) {
+        const uint32_t* lut = nullptr;
+        if (int rc = pulse::tfe_row_lut(&lut)) return rc;
+        hipLaunchKernelGGL(tfe_step4_kernel, grid1(n_boards), dim3(kBlock), 0, st, boards, total_score, actions, rewards, dones, n_boards, seed,
+                           board_id0, step_counter, lut);
+        return finish_launch("pulse_tfe_step");
+    }
     switch (n) {
     case 3: hipLaunchKernelGGL(tfe_step_kernel<3>, grid1(n_boards), dim3(kBlock), 0, st, boards, total_score, actions, rewards, dones, n_boards, seed, board_id0, step_counter, is_reset); break;
     case 4: hipLaunchKernelGGL(tfe_step_kernel<4>, grid1(n_boards), dim3(kBlock), 0, st, boards, total_score, actions, rewards, dones, n_boards, seed, board_id0, step_counter, is_reset); break;
     case 5: hipLaunchKernelGGL(tfe_step_kernel<5>, grid1(n_boards), dim3(kBlock), 0, st, boards, total_score, actions, rewards, dones, n_boards, seed, board_id0, step_counter, is_reset); break;
-    default: return pulse::fail(PULSE_EINVAL, "pulse_tfe: board side must be 3, 4 or 5");
+    default:
+        if (n < 2 || n > kTfeAnyMax) return pulse::fail(PULSE_EINVAL, "pulse_tfe: board side must be 2..8");
+        hipLaunchKernelGGL(tfe_step_any_kernel, grid1(n_boards), dim3(kBlock), 0, st, boards, total_score, actions, rewards, dones, n_boards, n, seed, board_id0, step_counter, is_reset);
     }
     return finish_launch("pulse_tfe");
 }

@@ -13,6 +13,9 @@ namespace pulse {
 int fail(int code, const char* msg);
 int fail_hip(int hip_error, const char* what);
 
+// envs.hip: the current device's row table of the packed 2048 move (tfe_device.h), built on first use
+int tfe_row_lut(const uint32_t** out);
+
 // stoprule.hip: a check point's partial done-counts (one uint32 per wavefront / workgroup) are written in stream order
 // into the slot `claim` hands out.  Their sum is published to the host by the NEXT launch on that stream: `claim` also
 // returns the previous check point's counts as a `carry`, which that launch sums and publishes in its first

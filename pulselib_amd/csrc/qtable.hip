@@ -36,8 +36,8 @@ __device__ __forceinline__ U4 philox4x32(uint64_t seed, uint64_t subseq, uint64_
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;   // (v_mad_u64_u32)
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(kBlock) void qtable_rollout_step_kernel(Entry* tabl
                                                                     int n_boards, double epsilon, double alpha, double gamma,
                                                                     uint64_t agent_seed, uint64_t agent_step, uint64_t env_seed, uint64_t env_step,
                                                                     uint64_t board_id0, int64_t* __restrict__ actions, int32_t* __restrict__ rewards,
-                                                                    uint8_t* __restrict__ dones, int64_t* __restrict__ slots_io, Deferred d) {
+                                                                    uint8_t* __restrict__ dones, int64_t* __restrict__ slots_io, Deferred d,
+                                                                    const uint32_t* __restrict__ lut) {
     using namespace pulse_tfe;
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= n_boards) return;
@@ -283,20 +284,36 @@ __global__ __launch_bounds__(kBlock) void qtable_rollout_step_kernel(Entry* tabl
     for (int i = 0; i < NB * NB; ++i) b[i] = bp[i];
     const uint64_t base = region_slots ? (uint64_t)g * region_slots : 0, slots = region_slots ? region_slots : capacity;
     long long s = slots_io[g];
-    if (s == -2) s = find_or_insert(table, base, slots, pack_cells(b, NB * NB));
+    // 4 x 4: the board packed to 64 bits (tfe_device.h) IS the state key, and the move / spawn / game-over test run on that word
+    // (four row-table lookups instead of ~900 per-cell selects); a wavefront that holds a board the packed form cannot (a tile
+    // that is no power of two in 2 .. 16,384) takes the cell form as a whole.
+    PackedBoard pb{0u, 0u};
+    bool fast = false;
+    if (NB == 4 && lut) { const bool ok = tfe_pack4(reinterpret_cast<const int (&)[16]>(b), pb); fast = !__any(!ok); }
+    if (s == -2) s = find_or_insert(table, base, slots, fast ? ((uint64_t)pb.hi << 32 | pb.lo) : pack_cells(b, NB * NB));
     double q[4] = {0.0, 0.0, 0.0, 0.0};
     if (s >= 0) { q[0] = table[s].q[0]; q[1] = table[s].q[1]; q[2] = table[s].q[2]; q[3] = table[s].q[3]; }
     const int a = choose_action(philox4x32(agent_seed, board_id0 + (uint64_t)g, agent_step), epsilon, q, s >= 0);
-    const int score = tfe_move<NB>(b, a);
     const U4 rnd = philox4x32(env_seed, board_id0 + (uint64_t)g, env_step);
-    tfe_spawn<NB>(b, rnd.x, rnd.y);                                                     // TFE.py:182 (always)
+    int score; bool over; uint64_t key_next;
+    if (fast) {
+        score = tfe_move_packed(pb, a, lut);
+        const int empty_before = tfe_spawn_packed(pb, rnd.x, rnd.y);                    // TFE.py:182 (always)
+        over = tfe_over_packed(pb, empty_before);
+        key_next = (uint64_t)pb.hi << 32 | pb.lo;
+        tfe_unpack4(pb, reinterpret_cast<int (&)[16]>(b));
+    } else {
+        score = tfe_move<NB>(b, a);
+        tfe_spawn<NB>(b, rnd.x, rnd.y);
+        over = tfe_over<NB>(b);
+        key_next = pack_cells(b, NB * NB);
+    }
     const int reward = score > 0 ? 31 - __clz(score) : 0;                                // TFE.py:185-187
-    const bool over = tfe_over<NB>(b);
 #pragma unroll
     for (int i = 0; i < NB * NB; ++i) bp[i] = b[i];
     total_score[g] += score;
     actions[g] = a; rewards[g] = reward; dones[g] = over;
-    const long long sn = find_or_insert(table, base, slots, pack_cells(b, NB * NB));
+    const long long sn = find_or_insert(table, base, slots, key_next);
     slots_io[g] = sn;
     if (s < 0) return;                                                                  // no room for the state: acted at random, learns nothing
     double mx = 0.0;
@@ -412,8 +429,10 @@ int pulse_qtable_rollout_step(const PulseQTable* q, const PulseQTableScratch* sc
     Entry* table = static_cast<Entry*>(q->entries);
     const dim3 grid((n_boards + kBlock - 1) / kBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
+    const uint32_t* lut = nullptr;
+    if (n == 4) if (int rc = pulse::tfe_row_lut(&lut)) return rc;
 #define PULSE_QT_ARGS table, q->capacity, q->region_slots, boards, total_score, n_boards, epsilon, alpha, gamma, agent_seed, agent_step, env_seed, \
-                      env_step, board_id0, actions, rewards, dones, slots_io, d
+                      env_step, board_id0, actions, rewards, dones, slots_io, d, lut
     if (n == 3) hipLaunchKernelGGL(qtable_rollout_step_kernel<3>, grid, block, 0, st, PULSE_QT_ARGS);
     else hipLaunchKernelGGL(qtable_rollout_step_kernel<4>, grid, block, 0, st, PULSE_QT_ARGS);
 #undef PULSE_QT_ARGS

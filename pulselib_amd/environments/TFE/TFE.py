@@ -1,7 +1,8 @@
 """MI355X 2048: the reference's environments/2048/TFE.py (cited as TFE.py:line) steps ONE board per
-env object through numba; here `TFEBatch` steps B boards per HIP launch (one lane per board, the 4x4
-board in 16 VGPRs, csrc/envs.hip: tfe_step_kernel) and `TFE` keeps the reference's single-board
-constructor / step signature on top of it (a batch of one).
+env object through numba; here `TFEBatch` steps B boards per HIP launch (one lane per board; 4 x 4 boards -- the
+size config/tfe.yaml runs -- packed to 64 bits with the move as four row-table lookups, csrc/envs.hip: tfe_step4_kernel;
+3 x 3 and 5 x 5 in registers; any other side from 2 to 8 by a plain per-lane loop) and `TFE` keeps the reference's
+single-board constructor / step signature on top of it (a batch of one).
 
 Tile spawns use Philox4x32-10(seed, board id, step counter) instead of numba's `random` (TFE.py:17-34):
 same distribution (uniform empty cell, 4 with probability 0.1), reproducible across CPU oracle and GPU."""
@@ -24,7 +25,7 @@ except Exception:  # pragma: no cover
 
 
 class TFEBatch:
-    """B independent n x n boards (n in 3..5) on the GPU."""
+    """B independent n x n boards (n in 2..8) on the GPU."""
 
     def __init__(self, device, batch_size, board_size=4, seed=0, board_id0=0):
         device = torch.device(device)
@@ -32,8 +33,8 @@ class TFEBatch:
             raise RuntimeError(f"pulselib_amd.TFEBatch runs on an MI355X ('cuda' device); got '{device}'. No CPU fallback.")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        if board_size not in (3, 4, 5):
-            raise ValueError("board_size must be 3, 4 or 5")
+        if not 2 <= board_size <= 8:
+            raise ValueError("board_size must be 2..8")
         self._lib = _native.lib()
         self.device, self.batch_size, self.n = device, batch_size, board_size
         self.seed, self.board_id0 = int(seed), int(board_id0)

@@ -80,9 +80,10 @@ def test_tfe_hip_matches_reference(golden_dir):
         np.testing.assert_array_equal(_np(info["score"]), fx["scores"][s].astype(np.int64), err_msg=f"step {s}")
 
 
-@pytest.mark.parametrize("n,B", [(4, 262144), (3, 1000), (5, 777)])
+@pytest.mark.parametrize("n,B", [(4, 262144), (3, 1000), (5, 777), (2, 500), (6, 300), (8, 129)])
 def test_tfe_hip_matches_oracle_at_scale(n, B):
-    """BASELINE.json config 3 size (262,144 boards of 4x4) plus odd board sizes."""
+    """BASELINE.json config 3 size (262,144 boards of 4x4: the packed-board kernel) plus the other board sides (3, 5: boards
+    in registers; 2, 6, 8: the any-side kernel -- the reference takes any board_height, TFE.py:112-131)."""
     from pulselib_amd.environments.TFE import TFEBatch
     env = TFEBatch(torch.device(DEV), B, n, seed=31, board_id0=1000)
     boards = np.zeros((B, n, n), dtype=np.int32)
@@ -103,6 +104,38 @@ def test_tfe_hip_matches_oracle_at_scale(n, B):
         np.testing.assert_array_equal(_np(info["score"]), score)
     # size-independent invariant: tile mass only grows by the spawned tile (2 or 4) per step
     assert (_np(env.boards).reshape(B, -1).sum(1) >= 4).all()
+
+
+def test_tfe_packed_kernel_steps_unusual_boards_cell_by_cell():
+    """The 4 x 4 kernel runs on the board packed to 4-bit log2 tiles; boards that form cannot hold -- a 1, a tile that is no
+    power of two, a negative, 32,768 and above -- must come out as the reference's cell-by-cell rule gives them (oracle),
+    lane by lane inside wavefronts whose other boards are ordinary ones, and 16,384 + 16,384 must merge to 32,768."""
+    from pulselib_amd.environments.TFE import TFEBatch
+    B, n = 4096, 4
+    env = TFEBatch(torch.device(DEV), B, n, seed=9, board_id0=77)
+    env.reset()
+    rng = np.random.default_rng(4)
+    boards = (2 ** rng.integers(1, 12, (B, n, n))).astype(np.int32) * (rng.random((B, n, n)) < 0.7)
+    odd = rng.choice(B, 600, replace=False)
+    for i, bd in enumerate(odd):                      # one unusual cell each, all kinds, spread over the wavefronts
+        r, c = rng.integers(0, 4, 2)
+        boards[bd, r, c] = (1, 3, 6, -2, 32768, 65536, 2 ** 20, 12, 16384, 5)[i % 10]
+    boards[5] = np.array([[16384, 16384, 16384, 16384], [2, 2, 4, 4], [0, 0, 0, 0], [8192, 8192, 0, 4096]])
+    boards = boards.astype(np.int32)
+    env.boards.copy_(torch.from_numpy(boards))
+    score = np.zeros(B, dtype=np.int64); rewards = np.zeros(B, dtype=np.int32); dones = np.zeros(B, dtype=np.uint8)
+    for s in range(12):
+        a = rng.integers(0, 4, B).astype(np.int64)
+        if s == 0:
+            a[5] = 0
+        b, r, d, _, info = env.step(torch.from_numpy(a))
+        orc.tfe_step(boards, score, a, rewards, dones, n, 9, s + 1, board_id0=77)
+        np.testing.assert_array_equal(_np(b), boards, err_msg=f"step {s}")
+        np.testing.assert_array_equal(_np(r), rewards, err_msg=f"step {s}")
+        np.testing.assert_array_equal(_np(d).astype(np.uint8), dones, err_msg=f"step {s}")
+        np.testing.assert_array_equal(_np(info["score"]), score, err_msg=f"step {s}")
+        if s == 0:
+            assert boards[5, 0].tolist()[:2] == [32768, 32768] and score[5] >= 65536 + 4 + 8 + 16384
 
 
 def test_tfe_single_board_wrapper_keeps_reference_signature():
@@ -332,7 +365,10 @@ def test_a_called_off_follow_up_launch_drops_its_updates_as_a_whole_and_fails_th
     assert time.perf_counter() - t0 < 2.0                          # 30 ms, not the default 3 s
     tab = agent.table()
     key = [k for k, v in tab.items() if v[a] != 0.0]
-    assert len(key) == 1 and abs(tab[key[0]][a] - 0.25 * 3.0) < 1e-12          # the winner's update alone: nothing half-combined
+    deferred = int(agent._scratch_tensors["count"][0])             # transitions that lost their compare-and-swap (> 1,024: the spread form)
+    assert 1024 < deferred < B
+    q0 = 3.0 * (1.0 - 0.75 ** (B - deferred))                      # the winners' updates, one after another -- and nothing half-combined
+    assert len(key) == 1 and abs(tab[key[0]][a] - q0) < 1e-12
     assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) > 0              # the accumulators stayed claimed ...
     agent._scratch.debug_meet_extra = 0
     with pytest.raises(RuntimeError, match="could not gather"):
@@ -341,7 +377,7 @@ def test_a_called_off_follow_up_launch_drops_its_updates_as_a_whole_and_fails_th
     assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) == 0 and int(agent._scratch_tensors["acc_cnt"].sum()) == 0   # ... and are clean now
     agent.get_actions(boards, 2)
     agent.update(nxt, rewards, term)                               # an ordinary launch again: all B transitions land
-    q1 = 0.75 + (1.0 - 0.75 ** B) * (3.0 - 0.75)
+    q1 = q0 + (1.0 - 0.75 ** B) * (3.0 - q0)
     assert abs(agent.table()[key[0]][a] - q1) < 1e-12
 
 

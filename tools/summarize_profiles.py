@@ -112,7 +112,7 @@ ev = newest(src / "envs_trace" / "*" / "*kernel_stats.csv")
 if ev:
     shutil.copy(ev, dst / "envs_kernel_stats.csv")
     summary = {}
-    for kn in ("qtable_rollout_step_kernel", "qtable_select_kernel", "qtable_update_kernel", "qtable_defer_kernel", "tfe_step_kernel", "particle2d_step_kernel",
+    for kn in ("qtable_rollout_step_kernel", "qtable_select_kernel", "qtable_update_kernel", "qtable_defer_kernel", "tfe_step4_kernel", "tfe_step_kernel", "particle2d_step_kernel",
                "blackjack_step_kernel"):
         c = {}
         for d, names in (("envs_fetch", ("FETCH_SIZE",)), ("envs_write", ("WRITE_SIZE",)),
