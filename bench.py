@@ -441,7 +441,7 @@ def recorded_traffic(tables, steps_per_launch, active_players):
     with the reason.  A summary whose mean steps per launch differs by up to 1.5 from this run's (short blocks cut a few
     launches to one check interval) is scaled by the ratio, and says so.  Returns (bytes or None, source string)."""
     want_sha = _sha_of_kernel_sources()
-    best, why = None, "no profiles/r*/step_kernel_profile*.json matches this workload"
+    best, best_rank, why = None, None, "no profiles/r*/step_kernel_profile*.json matches this workload"
     for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile*.json")):
         try:
             d = json.loads(f.read_text())
@@ -454,6 +454,10 @@ def recorded_traffic(tables, steps_per_launch, active_players):
             if d.get("kernel_source_sha256_16") != want_sha:
                 why = f"stale: {rel} was collected from other kernel sources ({d.get('kernel_source_sha256_16')} != {want_sha}); re-run tools/collect_profiles.sh"
                 continue
+            rank_of = (f.parent.name, -abs(have - steps_per_launch))           # the newest round's summary with the closest launch mix
+            if best_rank is not None and rank_of < best_rank:
+                continue
+            best_rank = rank_of
             best, why = float(d["traffic_bytes_per_launch"]) * steps_per_launch / have, rel
             if abs(have - steps_per_launch) > 0.05:
                 why += f" (scaled from {have:.2f} to {steps_per_launch:.2f} steps per launch)"

@@ -4,6 +4,11 @@
 same meaning, values passed through untouched (PyYAML reads `2e-4` as the STRING "2e-4"; the learner's constructor
 floats it, Player.py:224-225 -- ours does the same).  Keys the reference's file carries but its entry point never reads
 (CAPACITY, W1_DECAY, W2_DECAY, PLOT_FILENAME, SCORES_FILENAME) are accepted and ignored the same way.
+PLOTTING is accepted and has NO effect: the reference's entry point builds a MatplotlibPlotter from it and writes
+`rewards_learning_curve` / `total_chips_curve` images (scripts/Poker/trainGPU.py:152,120-131); the plotting service is outside
+this engine's scope, `main()` passes no plotter, and the curves' data -- the per-episode reward and chip
+sums -- are in the returned summary and in run_N.yaml instead.  `train_agent(_fused)` still take a `plotter` argument with the
+reference's `plot_learning_curve` interface for a caller that brings one.
 
 Keys this engine adds (all optional, defaults = the reference's behaviour where it has one):
   N_GPUS              1      one process per GPU; tables are sharded N_GAMES / N_GPUS per rank (sharding.py)

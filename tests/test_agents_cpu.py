@@ -13,3 +13,24 @@ def test_first_visit_returns_and_running_mean():
     mc.learn([(s0, 1, -1.0)])
     assert mc.values[s0] == (3.0 - 1.0) / 2 and mc.returns[s0] == [2.0, 2.0]
     assert mc.values[(0, 0, 0)] == 0.0            # defaultdict(float), as in the reference
+
+
+def test_first_visit_mc_reproduces_the_reference_class(golden_dir):
+    """tests/golden/fvmc.npz = the reference's FirstVisitMonteCarlo.learn (agents/MonteCarlo/FirstVisitMonteCarlo.py:13-31) run
+    on 3 x 40 seeded blackjack-shaped episodes (tests/golden/make_golden.py: make_fvmc): after episodes 0, 7 and 39 our class
+    holds the same states IN THE SAME DICT ORDER with bit-identical values and [sum, count] records."""
+    import numpy as np
+    g = np.load(golden_dir / "fvmc.npz")
+    for gi in range(3):
+        mc = FirstVisitMonteCarlo(gamma=float(g[f"g{gi}/gamma"]))
+        steps, at = g[f"g{gi}/steps"], 0
+        for ep, n in enumerate(g[f"g{gi}/episode_lengths"]):
+            rows = steps[at:at + n]
+            at += n
+            mc.learn([((int(r[0]), int(r[1]), int(r[2])), int(r[3]), float(r[4])) for r in rows])
+            if f"g{gi}/after{ep}/states" in g.files:
+                keys = [tuple(int(x) for x in k) for k in g[f"g{gi}/after{ep}/states"]]
+                assert list(mc.values) == keys, f"gamma {gi} episode {ep}: states / insertion order"
+                assert np.array_equal(np.array([mc.values[k] for k in keys]), g[f"g{gi}/after{ep}/values"])
+                assert np.array_equal(np.array([mc.returns[k] for k in keys], dtype=np.float64), g[f"g{gi}/after{ep}/returns"])
+        assert at == len(steps)

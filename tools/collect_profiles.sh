@@ -15,8 +15,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python bench.py --inproc --no-cpu-baseline --trainer-loop off --other-envs off --census off --min-timed-ms 50"
 P="rocprofv3 --kernel-trace --output-format csv"
 if [[ $PARTS == *poker* ]]; then
-for N in 65536 1048576; do for A in sampled 10; do
-  S="--tables $N --steps 600 --warmup 100 --active-players $A"; K=${N}_$A
+# ... and at 65,536 tables once more in the DRIVER's form (--steps 20 --warmup 5: blocks of 20 steps cut some launches to one
+# check interval, ~8-9 steps per launch instead of ~10), so that the driver line finds counter traffic of its own launch mix
+for F in long:65536 long:1048576 driver:65536; do N=${F#*:}; for A in sampled 10; do
+  if [[ $F == driver:* ]]; then S="--tables $N --steps 20 --warmup 5 --min-timed-ms 300 --active-players $A"; K=${N}_${A}_driver
+  else S="--tables $N --steps 600 --warmup 100 --active-players $A"; K=${N}_$A; fi
   rm -rf $OUT/trace_$K $OUT/fetch_$K $OUT/write_$K $OUT/sq_$K $OUT/sqw_$K
   echo "[collect] $(date +%T) $K: kernel trace"; $T $P --stats -d $OUT/trace_$K -- $B $S > $OUT/bench_trace_$K.log 2>&1
   echo "[collect] $(date +%T) $K: FETCH_SIZE"; $T $P --pmc FETCH_SIZE -d $OUT/fetch_$K -- $B $S > $OUT/bench_fetch_$K.log 2>&1

@@ -57,9 +57,9 @@ if cal_r and cal_w:
                    "write_correction": cal_bytes / (cal_w * 1024),
                    "how": "tools/pmc_calibrate.py: 512 MiB read / written with one dword per lane (the access shape of most of the kernel's loads and stores)"}
 
-for n in (65536, 1048576):
+for n, form in ((65536, ""), (1048576, ""), (65536, "_driver")):
     for mode in ("sampled", "10"):
-        k = f"{n}_{mode}"
+        k = f"{n}_{mode}{form}"
         stats = newest(src / f"trace_{k}" / "*" / "*kernel_stats.csv")
         if not stats:
             continue
