@@ -109,6 +109,9 @@ __device__ __forceinline__ void sort64_in_row(uint32_t (&a)[4], int lane) {
     cx(a[0], a[2]); cx(a[1], a[3]); cx(a[0], a[1]); cx(a[2], a[3]);
 }
 
+#ifndef PULSE_RESET_WIDE
+#define PULSE_RESET_WIDE 1        // 0: the per-wavefront narrow stores of rounds 1-3 (`make reset-narrow`: the A/B twin, tools/reset_ab.sh)
+#endif
 template <bool SHUFFLE>
 __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerView v, const PulsePokerResetOpts o) {
     __shared__ int32_t deck_s[kBlock / kLanes][52];
@@ -211,6 +214,13 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         *reinterpret_cast<int2*>(v.hands + row * 2) = make_int2(h0, h1);
     }
     if (inA) v.equities[(size_t)t * A + s] = 0.5f;                                      // :144
+#if PULSE_RESET_WIDE
+    // The [N] scalars and the board leave from an LDS image of the workgroup's 16 tables: one 64-byte store instruction per
+    // array by sixteen lanes of wavefront 0 instead of four 16-byte ones per array (-1.5 % .. -7 % at
+    // 1,048,576 tables, -2 % at 131,072, +-0 at 65,536 -- the kernel is bound by vector-instruction issue at every size)
+    __shared__ int32_t scal_s[4][kBlock / kLanes];
+    if (s == 0) { scal_s[0][g] = button; scal_s[1][g] = sb; scal_s[2][g] = bb; scal_s[3][g] = idx; }
+#else
     if (s < 5) v.board[t * 5 + s] = -1;                                                 // :95
     if (s == 0) {
         v.last_raise_size[t] = 1; v.deck_positions[t] = 2 * A; v.pots[t] = 1; v.stages[t] = 0;
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         v.highest[t] = 1; v.agg[t] = bb; v.acted[t] = 0; v.is_done[t] = 0; v.is_done_out[t] = 0;
         v.equity_dirty[t] = 1; v.prev_stacks[t] = 0; v.prev_invested[t] = 0;
     }
+#endif
     // first observation (:157 -> :159-179)
     float* __restrict__ ob = v.obs + (size_t)t * v.obs_size;
     const int a_h0 = grp_bcast(h0, idx), a_h1 = grp_bcast(h1, idx);
@@ -245,6 +256,20 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     // workgroup's tables sit in LDS, so the (table, seat) pairs are dealt to the workgroup's threads in order instead:
     // 16 A pairs -- one wavefront for A <= 4, two for A <= 8, ... -- and the wavefronts beyond skip all of it.
     // (Wavefronts of tables past the end of the batch have left; the barrier counts only those still running.)
+#if PULSE_RESET_WIDE
+    {
+        __syncthreads();                      // every lane has read its table's old button; the image is complete
+        const int t0w = blockIdx.x * (kBlock / kLanes), nw = min(kBlock / kLanes, v.n_games - t0w), e = (int)threadIdx.x;
+        if (e < nw) {
+            const int tt = t0w + e;
+            v.last_raise_size[tt] = 1; v.deck_positions[tt] = 2 * A; v.pots[tt] = 1; v.stages[tt] = 0;
+            v.button[tt] = scal_s[0][e]; v.sb[tt] = scal_s[1][e]; v.bb[tt] = scal_s[2][e]; v.idx[tt] = scal_s[3][e];
+            v.highest[tt] = 1; v.agg[tt] = scal_s[2][e]; v.acted[tt] = 0; v.is_done[tt] = 0; v.is_done_out[tt] = 0;
+            v.equity_dirty[tt] = 1; v.prev_stacks[tt] = 0; v.prev_invested[tt] = 0;
+        }
+        for (int i = e; i < nw * 5; i += kBlock) v.board[t0w * 5 + i] = -1;            // :95
+    }
+#endif
     if (!v.pre_board) return;
 #ifdef PULSE_FIVE_INDEX_LDS
     // experiment (profiles/README.md, r03): the evaluator's 16 KB index table staged in LDS by every workgroup
