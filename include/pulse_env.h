@@ -355,8 +355,9 @@ typedef struct PulseQTable {
     uint64_t capacity, region_slots;
 } PulseQTable;
 /* Scratch of a shared table (NULL for private regions): caller-owned device memory, zero-initialised once.
- * count uint32[4]; cells uint64[n]; targets double[n]; owner int32[n]; acc_key uint64[acc_slots]; acc_cnt
- * uint32[acc_slots]; acc_sum double[acc_slots]; n >= n_boards; acc_slots a power of two >= 2 n.  launch_index: the
+ * count uint32[64 + 2 * n / 256]; cells uint64[n]; targets double[n]; owner int32[n]; acc_key uint64[acc_slots]; acc_cnt
+ * uint32[acc_slots]; acc_sum double[acc_slots]; n >= n_boards, a multiple of 256 (the deferred list is kept in one segment
+ * per workgroup of the launch; at most 1,048,576 boards per launch); acc_slots a power of two >= 2 n.  launch_index: the
  * caller counts its update / rollout_step launches on this scratch (0, 1, 2, ...: its parity picks the list).
  * A long list of deferred transitions is combined by 64 workgroups that meet inside the follow-up launch; if they cannot
  * gather within wait_ticks (a co-tenant on the GPU) the meeting is called off as a whole, that launch's combined updates

@@ -52,11 +52,11 @@ class QLearningBatch:
         self._q = _native.QTable(self.entries.data_ptr(), self.capacity, self.region_slots)
         self._scratch, self._scratch_tensors, self._launches, self._carried = None, None, 0, False
         if not private_tables:                                              # shared table: the deferred-update scratch (pulse_env.h)
-            n = batch_size
+            n = -(-batch_size // 256) * 256                                 # the deferred list is kept in segments of 256 (pulse_env.h)
             acc = 1
             while acc < 2 * max(n, 1):
                 acc *= 2
-            t = dict(count=torch.zeros(4, dtype=torch.int32, device=device), cells=torch.zeros(n, dtype=torch.int64, device=device),
+            t = dict(count=torch.zeros(64 + 2 * (n // 256), dtype=torch.int32, device=device), cells=torch.zeros(n, dtype=torch.int64, device=device),
                      targets=torch.zeros(n, dtype=torch.float64, device=device), owner=torch.zeros(n, dtype=torch.int32, device=device),
                      acc_key=torch.zeros(acc, dtype=torch.int64, device=device), acc_cnt=torch.zeros(acc, dtype=torch.int32, device=device),
                      acc_sum=torch.zeros(acc, dtype=torch.float64, device=device))

@@ -78,6 +78,10 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 // thread into a walk over the whole table (262,144 threads x 2^24 slots: a launch that never ends); past the
 // limit the state counts as "no room" like a full region.
 constexpr uint64_t kMaxProbe = 4096;
+// (Tried and dropped, DESIGN.md section 3.4: a "shared by several boards" hint kept in the entry's spare words by plain loads
+// and stores at the lookup of the state a move led to, so that the next launch sends the updates of a hot entry straight to the
+// combine path instead of racing for a compare-and-swap -- 233 -> 140 us at the second step after a reset, but +8 us at EVERY
+// step for dirtying the looked-up line, and the racy visitor count rarely passed 8 across the eight L2s.)
 __device__ __forceinline__ long long find_or_insert(Entry* table, uint64_t base, uint64_t slots, uint64_t key) {
     uint64_t h = mix64(key) & (slots - 1);
     const uint64_t limit = slots < kMaxProbe ? slots : kMaxProbe;
@@ -103,8 +107,14 @@ __device__ __forceinline__ int choose_action(const U4& r, double epsilon, const 
 }
 
 // ---- deferred updates of a shared table (see the header comment) -------------------------------------------------
+// The list of a launch's deferred transitions is kept in SEGMENTS, one per workgroup of the launch (slots 256 w .. 256 w + 255
+// for workgroup w, its length in count[kCountWg + parity * W + w]): positions come from a counter in LDS, the lengths leave as
+// plain stores.  (One list with one global counter: a returning atomic per wavefront on ONE address, ~7 ns apiece one after
+// the other -- 28 of the 72 us of a launch while most wavefronts still had a loser, i.e. for the first ~25 steps after a reset.)
+constexpr int kCountMeet = 0;       // count[0..8) / [8..16): the follow-up launch's arrival counters, by parity
+constexpr int kCountWg = 64;        // count[64 + parity * W + w]: deferred transitions of workgroup w (W = ceil(n / 256))
 struct Deferred {                 // per-launch scratch, owned by the caller (PulseQTableScratch)
-    unsigned int* count;          // [4]: deferred transitions of the even / odd launch, then the two meeting counters of the follow-up launch
+    unsigned int* count;          // [64 + 2 W], see above
     unsigned long long* cells;    // [n]: entry index * 4 + action
     double* targets;              // [n]
     int* owner;                   // [n]: accumulator index if this transition claimed its cell, else -1
@@ -113,105 +123,161 @@ struct Deferred {                 // per-launch scratch, owned by the caller (Pu
     double* acc_sum;              // [acc_slots]
     unsigned int acc_slots;       // power of two >= 2 n
     int parity;
+    int n_wg;                     // W: workgroups of the launch that filled the list (= segments)
     long long wait_ticks;         // how long a workgroup of the follow-up launch waits at its meeting (100 MHz ticks)
     unsigned int extra_arrivals;  // test hook: arrivals the meeting expects beyond the grid's (never met)
     long long* gave_up;           // pinned host word, += 1 by a follow-up launch whose meeting was called off
+    int ablate;                   // timing-only diagnostics (PulseQTableScratch.reserved0; results are then NOT valid updates):
+                                  // 1 = no compare-and-swap, every update is deferred; 2 = losers are dropped, not listed; 4 = new states are not inserted
 };
-constexpr unsigned int kDeferOff = 0x80000000u;   // the meeting counter with this bit: called off
+constexpr unsigned int kDeferOff = 0x80000000u;   // a meeting counter with this bit: called off
 
-// q[s][a] <- q + alpha (target - q): race-free regions write, shared tables try ONE compare-and-swap and defer on a loss
-__device__ __forceinline__ void apply_update(Entry* table, long long s, int a, double target, double alpha, bool shared_table, const Deferred& d) {
-    double* cell = &table[s].q[a & 3];
+// q[s][a] <- q + alpha (target - q): race-free regions write, shared tables try ONE compare-and-swap and defer on a loss.
+// Called by EVERY thread of the workgroup (`live` = this thread has a transition): the losers' list positions come from the
+// workgroup's LDS counter `wg_n` (zeroed by the caller before a barrier), the segment's length is stored by finish_deferred.
+__device__ __forceinline__ void apply_update(Entry* table, bool live, long long s, int a, double target, double alpha, bool shared_table, const Deferred& d,
+                                             unsigned int* wg_n) {
     if (!shared_table) {
+        if (!live) return;
+        double* cell = &table[s].q[a & 3];
         const double old = *cell;
         *cell = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));                       // numba.py:38-39
         return;
     }
-    unsigned long long* raw = reinterpret_cast<unsigned long long*>(cell);
-    const unsigned long long seen = *raw;
-    const double old = __longlong_as_double((long long)seen);
-    const double upd = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));
-    const bool lost = atomicCAS(raw, seen, (unsigned long long)__double_as_longlong(upd)) != seen;
-    // append the losers to the launch's list: ONE counter increment per wavefront (262,144 increments of one word took
-    // 650 us at the first step after a reset, where nearly every board loses)
+    bool lost = false;
+    if (live) {
+        unsigned long long* raw = reinterpret_cast<unsigned long long*>(&table[s].q[a & 3]);
+        const unsigned long long seen = *raw;
+        const double old = __longlong_as_double((long long)seen);
+        const double upd = __dadd_rn(old, __dmul_rn(alpha, __dsub_rn(target, old)));
+        lost = true;
+        if (!(d.ablate & 1)) lost = atomicCAS(raw, seen, (unsigned long long)__double_as_longlong(upd)) != seen;
+        if (d.ablate & 2) lost = false;
+    }
     const unsigned long long losers = __ballot(lost);
     if (!lost) return;
     const int lane = (int)(threadIdx.x & 63u);
     const int leader = __ffsll((long long)losers) - 1;
     unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(d.count + d.parity, (unsigned int)__popcll(losers));
+    if (lane == leader) base = atomicAdd(wg_n, (unsigned int)__popcll(losers));              // LDS
     base = (unsigned int)__shfl((int)base, leader);
-    const unsigned int at = base + (unsigned int)__popcll(losers & ((1ull << lane) - 1ull));
+    const unsigned int at = blockIdx.x * kBlock + base + (unsigned int)__popcll(losers & ((1ull << lane) - 1ull));
     d.cells[at] = (unsigned long long)s * 4ull + (unsigned long long)(a & 3);
     d.targets[at] = target;
+}
+// after apply_update, by every thread of the workgroup: the segment's length leaves (also when it is zero)
+__device__ __forceinline__ void finish_deferred(const Deferred& d, unsigned int* wg_n) {
+    if (!d.count) return;
+    __syncthreads();
+    if (threadIdx.x == 0) d.count[kCountWg + d.parity * d.n_wg + blockIdx.x] = *wg_n;
 }
 
 // The deferred transitions of a launch, in ONE follow-up launch of kDeferBlocks workgroups: (1) every transition finds (or
 // claims) the accumulator of its cell and adds its target; (2) the transition that claimed a cell applies the combined
-// update and frees the accumulator.  Between the phases the workgroups meet at a counter in the scratch -- they are all
-// resident (one per CU at most) -- but ONLY when something was deferred: with an empty list (boards spread over distinct
-// states: the usual case) every workgroup reads one word and leaves.
-constexpr int kDeferBlocks = 64;
+// update and frees the accumulator.  Between the phases the workgroups meet at eight counters in the scratch -- they are all
+// resident (one per CU at most) -- but ONLY when the list is long: a short one (the steady state: a few popular states are
+// still shared by some boards) is ONE workgroup's work with a workgroup barrier between the phases, and with an empty one
+// every workgroup sums the segment lengths and leaves.
+constexpr int kDeferBlocks = 64;      // (256 workgroups: the follow-up launch took 50 us instead of 18 on the lists of steps 10..60 -- the meeting grows with its members)
 constexpr unsigned int kDeferSolo = 1024;
 __global__ __launch_bounds__(kBlock) void qtable_defer_kernel(Entry* table, Deferred d, double alpha) {
-    const unsigned int n = d.count[d.parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.count[d.parity ^ 1] = 0u; d.count[2 + (d.parity ^ 1)] = 0u; }   // the next launch's list and meeting point
+    // the segments' first item numbers (exclusive prefix sum of their lengths; every workgroup computes it for itself): item i of
+    // the launch's list = slot 256 w + (i - seg_start[w]) for the segment w that holds it -- the items are dealt to the threads
+    // densely (a thread per segment slot would leave most lanes idle for sixteen dependent rounds: 17 -> 57 us when tried)
+    __shared__ unsigned int seg_start[4097];
+    __shared__ unsigned int wave_tot[kBlock / 64];
+    const unsigned int* lens = d.count + kCountWg + d.parity * d.n_wg;
+    const int chunk = (d.n_wg + kBlock - 1) / kBlock;                          // <= 16 segments per thread
+    unsigned int len[16], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int w = (int)threadIdx.x * chunk + k;
+        len[k] = (k < chunk && w < d.n_wg) ? lens[w] : 0u;
+        mine += len[k];
+    }
+    unsigned int incl = mine;                                                   // inclusive scan over the workgroup's threads
+    for (int m = 1; m < 64; m <<= 1) { const unsigned int up = (unsigned int)__shfl_up((int)incl, m); if ((int)(threadIdx.x & 63) >= m) incl += up; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    if (blockIdx.x == 0 && threadIdx.x < 8) d.count[kCountMeet + 8 * (d.parity ^ 1) + threadIdx.x] = 0u;      // the next launch's meeting point
+    __syncthreads();
+    unsigned int before = 0, n = 0;
+    for (int k = 0; k < kBlock / 64; ++k) { if (k < (int)(threadIdx.x >> 6)) before += wave_tot[k]; n += wave_tot[k]; }
     if (n == 0u) return;
-    // A short list (the steady state: a few popular states are still shared by some boards) is ONE workgroup's work -- the
-    // others leave, and the two phases are separated by a workgroup barrier; only a long list (the steps after a reset) is
-    // spread over all workgroups, which then meet at the counter (that meeting alone costs ~25 us).
+    unsigned int run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int w = (int)threadIdx.x * chunk + k;
+        if (k < chunk && w < d.n_wg) seg_start[w] = run;
+        run += len[k];
+    }
+    if (threadIdx.x == 0) seg_start[d.n_wg] = n;
+    __syncthreads();
     const bool solo = n <= kDeferSolo;
     if (solo && blockIdx.x != 0) return;
-    const unsigned int first = solo ? threadIdx.x : blockIdx.x * kBlock + threadIdx.x, stride = solo ? kBlock : gridDim.x * kBlock;
-    for (unsigned int i = first; i < n; i += stride) {
+    // solo: the one workgroup takes all items; spread: item i goes to thread i mod (grid x 256)
+    auto for_my_items = [&](auto&& body) {
+        const unsigned int first = solo ? threadIdx.x : blockIdx.x * kBlock + threadIdx.x, stride = solo ? kBlock : gridDim.x * kBlock;
+        for (unsigned int i = first; i < n; i += stride) {
+            int lo = 0, hi = d.n_wg;                                            // the last segment that starts at or before item i
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= i) lo = mid; else hi = mid; }
+            body((unsigned int)lo * kBlock + (i - seg_start[lo]));
+        }
+    };
+    for_my_items([&](unsigned int i) {
         const unsigned long long cell = d.cells[i], tag = cell + 1ull;
         unsigned int h = (unsigned int)mix64(cell) & (d.acc_slots - 1u);
-        int mine = -1;
+        int claimed = -1;
         for (;;) {                                        // acc_slots >= 2 n: a free slot always exists
             unsigned long long cur = d.acc_key[h];
-            if (cur == 0ull) { cur = atomicCAS(d.acc_key + h, 0ull, tag); if (cur == 0ull) { mine = (int)h; break; } }
+            if (cur == 0ull) { cur = atomicCAS(d.acc_key + h, 0ull, tag); if (cur == 0ull) { claimed = (int)h; break; } }
             if (cur == tag) break;
             h = (h + 1u) & (d.acc_slots - 1u);
         }
         atomicAdd(d.acc_cnt + h, 1u);
         atomicAdd(d.acc_sum + h, d.targets[i]);
-        d.owner[i] = mine;
-    }
+        d.owner[i] = claimed;
+    });
     __threadfence();
     __syncthreads();
     if (!solo) {
-        // All or nothing: phase 2 runs iff the counter read exactly full.  A workgroup whose wait runs out marks the counter
-        // (compare-and-swap from the short value it read: the mark lands before the missing arrival or not at all), after
-        // which it never reads full: no owner applies `sum / k` from accumulators other workgroups are still adding to.
-        // The accumulators then stay claimed; the host finds the pinned count changed, clears them and fails its next call.
+        // All or nothing: phase 2 runs iff all eight counters read exactly full.  A workgroup whose wait runs out marks a counter
+        // that is still short (compare-and-swap from the value it read: the mark lands before the missing arrival or not at
+        // all), after which that counter never reads full: no owner applies `sum / k` from accumulators other workgroups are
+        // still adding to.  The accumulators then stay claimed; the host finds the pinned count changed, clears them and
+        // fails its next call.  (Eight counters: arrivals on ONE address cost the meeting ~25 us.)
         __shared__ int go_s;
-        if (threadIdx.x == 0) {
-            unsigned int* meet = d.count + 2 + d.parity;
-            const unsigned int want = gridDim.x + d.extra_arrivals;
-            atomicAdd(meet, 1u);
+        if (threadIdx.x < 64) {
+            unsigned int* meet = d.count + kCountMeet + 8 * d.parity;
+            if (threadIdx.x == 0) atomicAdd(meet + (blockIdx.x & 7), 1u);
+            unsigned int want = (gridDim.x + 7 - (threadIdx.x & 7)) / 8;
+            if (threadIdx.x == 0) want += d.extra_arrivals;
             int go = 0;
             for (const long long t0 = wall_clock64();;) {        // (100 MHz)
-                const unsigned int got = __hip_atomic_load(meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (got & kDeferOff) break;
-                if (got == want) { go = 1; break; }
+                const unsigned int got = threadIdx.x < 8 ? __hip_atomic_load(meet + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+                if (__ballot((got & kDeferOff) != 0u) != 0ull) break;
+                const unsigned long long short_of = __ballot(got != want);
+                if (short_of == 0ull) { go = 1; break; }
                 if (wall_clock64() - t0 > d.wait_ticks) {
-                    if (atomicCAS(meet, got, got | kDeferOff) == got) {
-                        if (d.gave_up) __hip_atomic_fetch_add(d.gave_up, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const int first = __ffsll((long long)short_of) - 1;
+                    unsigned int marked = 0u;
+                    if ((int)threadIdx.x == first) marked = atomicCAS(meet + threadIdx.x, got, got | kDeferOff) == got ? 1u : 0u;
+                    if (__ballot(marked != 0u) != 0ull) {
+                        if ((int)threadIdx.x == first && d.gave_up) __hip_atomic_fetch_add(d.gave_up, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                     continue;
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
-            go_s = go;
+            if (threadIdx.x == 0) go_s = go;
         }
         __syncthreads();
         if (!go_s) return;
     }
     __threadfence();
-    for (unsigned int i = first; i < n; i += stride) {
+    for_my_items([&](unsigned int i) {
         const int h = d.owner[i];
-        if (h < 0) continue;
+        if (h < 0) return;
         const unsigned long long cell = d.cells[i];
         const unsigned int k = __hip_atomic_load(d.acc_cnt + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double sum = __hip_atomic_load(d.acc_sum + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -222,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void qtable_defer_kernel(Entry* table, Defe
         const double w = k == 1u ? alpha : 1.0 - pow(1.0 - alpha, (double)k);
         *q = __dadd_rn(old, __dmul_rn(w, __dsub_rn(mean, old)));
         d.acc_key[h] = 0ull; d.acc_cnt[h] = 0u; d.acc_sum[h] = 0.0;
-    }
+    });
 }
 
 __global__ __launch_bounds__(kBlock) void qtable_select_kernel(Entry* table, uint64_t capacity, uint64_t region_slots,
@@ -246,21 +312,28 @@ __global__ __launch_bounds__(kBlock) void qtable_update_kernel(Entry* table, uin
                                                               const int32_t* __restrict__ rewards, const int32_t* __restrict__ next_boards,
                                                               const uint8_t* __restrict__ terminal, int n_boards, int cells, double alpha,
                                                               double gamma, Deferred d) {
+    __shared__ unsigned int wg_n;
+    if (threadIdx.x == 0) wg_n = 0u;
+    __syncthreads();
     const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= n_boards) return;
-    const long long s = slots_s[g];
-    if (s < 0) return;
-    const uint64_t base = region_slots ? (uint64_t)g * region_slots : 0, slots = region_slots ? region_slots : capacity;
-    // QLearningNumba.py:28-37 touches q[next_state] even for terminal transitions (defaultdict insert)
-    const long long sn = find_or_insert(table, base, slots, pack_board(next_boards + (size_t)g * cells, cells));
-    double mx = 0.0;
-    if (sn >= 0) {
-        mx = table[sn].q[0];
-        for (int i = 1; i < 4; ++i) if (table[sn].q[i] > mx) mx = table[sn].q[i];             // numba.py:28-31
+    const long long s = g < n_boards ? slots_s[g] : -1;
+    const bool live = s >= 0;
+    double target = 0.0; int a = 0;
+    if (live) {
+        const uint64_t base = region_slots ? (uint64_t)g * region_slots : 0, slots = region_slots ? region_slots : capacity;
+        // QLearningNumba.py:28-37 touches q[next_state] even for terminal transitions (defaultdict insert)
+        const long long sn = find_or_insert(table, base, slots, pack_board(next_boards + (size_t)g * cells, cells));
+        double mx = 0.0;
+        if (sn >= 0) {
+            mx = table[sn].q[0];
+            for (int i = 1; i < 4; ++i) if (table[sn].q[i] > mx) mx = table[sn].q[i];             // numba.py:28-31
+        }
+        const double reward = (double)rewards[g];
+        target = terminal[g] ? reward : __dadd_rn(reward, __dmul_rn(gamma, mx));                 // numba.py:33-36
+        a = (int)(actions[g] & 3);
     }
-    const double reward = (double)rewards[g];
-    const double target = terminal[g] ? reward : __dadd_rn(reward, __dmul_rn(gamma, mx));       // numba.py:33-36
-    apply_update(table, s, (int)(actions[g] & 3), target, alpha, region_slots == 0, d);
+    apply_update(table, live, s, a, target, alpha, region_slots == 0, d, &wg_n);
+    finish_deferred(d, &wg_n);
 }
 
 // One roll-out step of B learners in one launch: what select -> pulse_tfe_step -> update do in three, with the board in
@@ -276,8 +349,11 @@ __global__ __launch_bounds__(kBlock) void qtable_rollout_step_kernel(Entry* tabl
                                                                     uint8_t* __restrict__ dones, int64_t* __restrict__ slots_io, Deferred d,
                                                                     const uint32_t* __restrict__ lut) {
     using namespace pulse_tfe;
+    __shared__ unsigned int wg_n;
+    if (threadIdx.x == 0) wg_n = 0u;
+    __syncthreads();
     const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= n_boards) return;
+    if (g >= n_boards) { apply_update(table, false, -1, 0, 0.0, alpha, region_slots == 0, d, &wg_n); finish_deferred(d, &wg_n); return; }
     int b[NB * NB];
     int32_t* bp = boards + (size_t)g * NB * NB;
 #pragma unroll
@@ -313,16 +389,16 @@ __global__ __launch_bounds__(kBlock) void qtable_rollout_step_kernel(Entry* tabl
     for (int i = 0; i < NB * NB; ++i) bp[i] = b[i];
     total_score[g] += score;
     actions[g] = a; rewards[g] = reward; dones[g] = over;
-    const long long sn = find_or_insert(table, base, slots, key_next);
+    const long long sn = (d.ablate & 4) ? (long long)(base + (mix64(key_next) & (slots - 1))) : find_or_insert(table, base, slots, key_next);
     slots_io[g] = sn;
-    if (s < 0) return;                                                                  // no room for the state: acted at random, learns nothing
-    double mx = 0.0;
-    if (sn >= 0) {
+    double mx = 0.0;                                                                    // (s < 0: no room for the state: acted at random, learns nothing)
+    if (s >= 0 && sn >= 0) {
         mx = table[sn].q[0];
         for (int i = 1; i < 4; ++i) if (table[sn].q[i] > mx) mx = table[sn].q[i];
     }
     const double target = over ? (double)reward : __dadd_rn((double)reward, __dmul_rn(gamma, mx));
-    apply_update(table, s, a, target, alpha, region_slots == 0, d);
+    apply_update(table, s >= 0, s, a, target, alpha, region_slots == 0, d, &wg_n);
+    finish_deferred(d, &wg_n);
 }
 
 int finish_launch(const char* what) {
@@ -356,6 +432,9 @@ int deferred_of(const PulseQTable* q, const PulseQTableScratch* sc, int32_t n_bo
         return pulse::fail(PULSE_EINVAL, "PulseQTable: a shared table needs its PulseQTableScratch");
     if (sc->n < (uint32_t)n_boards || sc->acc_slots < 2u * (uint32_t)n_boards || (sc->acc_slots & (sc->acc_slots - 1u)))
         return pulse::fail(PULSE_EINVAL, "PulseQTableScratch: need n >= n_boards and acc_slots a power of two >= 2 n_boards");
+    const int n_wg = (n_boards + kBlock - 1) / kBlock;
+    if (n_wg > 4096) return pulse::fail(PULSE_EINVAL, "PulseQTable: a shared table takes at most 1,048,576 boards per launch");
+    if (sc->n % kBlock) return pulse::fail(PULSE_EINVAL, "PulseQTableScratch: n must be a multiple of 256 (the list is kept in segments of 256)");
     if (!g_defer_gave_up) {
         void* p = nullptr;
         if (hipHostMalloc(&p, sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
@@ -373,9 +452,9 @@ int deferred_of(const PulseQTable* q, const PulseQTableScratch* sc, int32_t n_bo
                                             "accumulators have been cleared");
     }
     *d = Deferred{sc->count, reinterpret_cast<unsigned long long*>(sc->cells), sc->targets, sc->owner,
-                  reinterpret_cast<unsigned long long*>(sc->acc_key), sc->acc_cnt, sc->acc_sum, sc->acc_slots, (int)(launch_index & 1u),
+                  reinterpret_cast<unsigned long long*>(sc->acc_key), sc->acc_cnt, sc->acc_sum, sc->acc_slots, (int)(launch_index & 1u), n_wg,
                   sc->wait_ticks > 0 ? (long long)sc->wait_ticks : 300000000ll, sc->debug_meet_extra > 0 ? (unsigned int)sc->debug_meet_extra : 0u,
-                  g_defer_gave_up};
+                  g_defer_gave_up, sc->reserved0};
     return 0;
 }
 void launch_deferred(Entry* table, const Deferred& d, double alpha, hipStream_t st) {

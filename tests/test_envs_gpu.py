@@ -314,6 +314,62 @@ def test_fused_rollout_step_equals_select_step_update(private):
     assert float(_np(a1.values).max()) > 0
 
 
+def test_fused_rollout_step_at_config3_size():
+    """BASELINE config 3's size, the launch bench.py times (`tfe_qlearning_rollout_step`), held to its definition directly:
+    (i) private tables (64 slots per board: 20 steps visit at most 41 states), 262,144 boards: the ONE-launch step equals
+    get_actions + env.step + update call for call for 20 steps -- actions, boards, rewards, done flags, scores -- and leaves
+    bit-identical tables (utils/numba.py:5-39; TFE.py:152-189);
+    (ii) the shared table at the step right after a reset, where all 262,144 boards sit in a few hundred two-tile states and
+    ~1,000 of them update one entry in the same launch (gamma = 0 and a greedy policy on an empty table: every board of a
+    state takes action 0 and has the same target, the move's reward): whatever mix of compare-and-swap winners and combined
+    losers an entry saw, its value must be the k updates one after another, t (1 - (1 - alpha)^k) -- no update lost, none
+    applied twice (QLearningNumba.py:28-37 per board)."""
+    from pulselib_amd.agents import QLearningBatch
+    from pulselib_amd.environments.TFE import TFEBatch
+    B, n = 262144, 4
+    dev = torch.device(DEV)
+    cfg = {"ALPHA": 0.1, "GAMMA": 0.99, "EPSILON": 0.1}
+    kw = dict(config=cfg, private_tables=True, slots=64, seed=17)
+    e1, e2 = TFEBatch(dev, B, n, seed=5), TFEBatch(dev, B, n, seed=5)
+    a1, a2 = QLearningBatch(dev, B, n, **kw), QLearningBatch(dev, B, n, **kw)
+    e1.reset(); e2.reset()
+    for s in range(20):
+        acts = a1.get_actions(e1.boards, s).clone()
+        nb, r, d, _, _ = e1.step(acts)
+        a1.update(nb, r, d)
+        nb2, r2, d2, _, _ = a2.rollout_step(e2, s)
+        assert torch.equal(a2.actions, acts) and torch.equal(nb2, nb) and torch.equal(r2, r) and torch.equal(d2, d), f"step {s}"
+        assert torch.equal(e2.total_score, e1.total_score)
+    assert torch.equal(a2.keys, a1.keys) and torch.equal(a2.values.view(torch.int64), a1.values.view(torch.int64))
+    assert int((a1.keys != 0).sum()) > 10 * B
+    del a1, a2, e1
+    torch.cuda.empty_cache()
+    # (ii)
+    alpha = 0.25
+    env = e2
+    env.reset()
+    agent = QLearningBatch(dev, B, n, config={"ALPHA": alpha, "GAMMA": 0.0, "EPSILON": 0.0}, slots=1 << 22, seed=3)
+    start = _np(env.boards).reshape(B, 16).astype(np.int64)
+    logs = np.where(start > 0, np.log2(np.maximum(start, 1)).astype(np.int64), 0)
+    keys = (logs << (4 * np.arange(16, dtype=np.int64))).sum(axis=1)
+    _, rew, _, _, _ = agent.rollout_step(env, 0)
+    assert int(agent.actions.abs().max()) == 0                              # greedy on an empty table: the first maximum
+    rew = _np(rew).astype(np.float64)
+    uniq, inverse, counts = np.unique(keys, return_inverse=True, return_counts=True)
+    assert len(uniq) <= 480 and counts.max() > 500
+    target = np.zeros(len(uniq)); target[inverse] = rew                     # the same for every board of a state
+    assert np.array_equal(target[inverse], rew)
+    table = agent.table()
+    checked = 0
+    for key, k, t in zip(uniq.tolist(), counts.tolist(), target.tolist()):
+        want = t * (1.0 - (1.0 - alpha) ** k)
+        got = table[key & (2**64 - 1)]
+        assert abs(got[0] - want) <= 1e-12 * max(1.0, abs(want)) and got[1] == got[2] == got[3] == 0.0, (hex(key), k, t, got)
+        checked += t > 0
+    assert checked > 20                                                     # states whose move to the left merges two tiles
+    assert int(agent._scratch_tensors["acc_key"].ne(0).sum()) == 0          # every accumulator was applied and freed
+
+
 def test_shared_table_combines_simultaneous_updates_of_one_entry():
     """Many boards in the SAME state taking the SAME action in one launch (what happens right after reset): one update
     goes through alone, the others are combined per cell -- with equal targets the result is the k + 1 updates applied one
@@ -365,7 +421,8 @@ def test_a_called_off_follow_up_launch_drops_its_updates_as_a_whole_and_fails_th
     assert time.perf_counter() - t0 < 2.0                          # 30 ms, not the default 3 s
     tab = agent.table()
     key = [k for k, v in tab.items() if v[a] != 0.0]
-    deferred = int(agent._scratch_tensors["count"][0])             # transitions that lost their compare-and-swap (> 1,024: the spread form)
+    W = B // 256                                                   # launch 0: the segment lengths of parity 0 (pulse_env.h: PulseQTableScratch.count)
+    deferred = int(agent._scratch_tensors["count"][64:64 + W].sum())   # transitions that lost their compare-and-swap (> 1,024: the spread form)
     assert 1024 < deferred < B
     q0 = 3.0 * (1.0 - 0.75 ** (B - deferred))                      # the winners' updates, one after another -- and nothing half-combined
     assert len(key) == 1 and abs(tab[key[0]][a] - q0) < 1e-12

@@ -19,6 +19,9 @@ env = TFEBatch(dev, B, 4, seed=0)
 agent = QLearningBatch(dev, B, 4, slots=1 << 26, seed=0)
 env.reset()
 FUSED = "--fused" in sys.argv
+for a in sys.argv:
+    if a.startswith("--ablate="):          # timing-only diagnostics of csrc/qtable.hip (Deferred.ablate): the table is NOT valid afterwards
+        agent._scratch.reserved0 = int(a.split("=")[1])
 ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(STEPS)]
 for t in range(STEPS):
     if FUSED:
