@@ -481,6 +481,27 @@ int pulse_qnet_train_grads(const PulseQNetTrain* t, const float* states, int64_t
                            uint64_t table_id0, uint8_t* terminated, double* reward_sum, void* stream);
 int pulse_qnet_train_apply(const PulseQNetTrain* t, void* stream);
 
+/* The first half of the trainer's step with the learner in it as ONE launch (scripts/Poker/trainGPU.py:79-83 with the learner at
+ * a seat: build_actions -> env.step): pulse_qnet_act_select on the observation act->states (the learner's actions into
+ * `actions`, the trainer's mask into act->row_mask_out, the training launch's row lists into act->select_scratch) followed by
+ * pulse_poker_policy_step on `v` -- the same results word for word; the workgroup that picks the actions of a window of 128
+ * tables steps those tables itself, so nothing grid-wide lies between the two and the tables' state travels from HBM while
+ * the forward runs.  Needs n_games % 128 == 0, max_players <= 10, 16-byte aligned fp32 rows of 16..40 inputs (a multiple of
+ * 8); PULSE_EINVAL otherwise: make the two calls instead.  act->states must NOT be the buffer v->obs writes (the trainer's
+ * double-buffered observations).  stoprule: as pulse_poker_rollout (the done tables after the step are counted for it by the
+ * launch itself), or NULL. */
+typedef struct PulseQNetAct {
+    const float* states; int64_t row_stride;     /* device fp32 rows, row_stride floats apart: the observation the learner acts (and trains) on */
+    const int32_t* seat_idx; int32_t q_seat;     /* rows with seat_idx[r] == q_seat are the learner's */
+    float epsilon;
+    uint64_t seed, step, table_id0;              /* the learner's exploration stream (pulse_qnet_act) */
+    const uint8_t* terminated; uint8_t* row_mask_out;
+    int32_t* select_scratch; int64_t select_words;
+} PulseQNetAct;
+int pulse_poker_act_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter,
+                                uint64_t table_id0, int64_t* actions, float* rewards, const PulseQNet* net,
+                                const PulseQNetAct* act, void* stoprule, void* stream);
+
 /* ---- Particle2D (environments/Particle2D/Particle2D.py:22-30) ---------------------------------- */
 int pulse_particle2d_step(float* state, const float* action, int32_t* steps, float* obs_out, float* rewards,
                           uint8_t* terminated, int32_t n, float dt, int32_t max_steps, void* stream);

@@ -70,6 +70,12 @@ class QNetTrain(C.Structure):
         ("separate_apply", C.c_int32), ("meet_wait_ticks", C.c_int64), ("debug_meet_extra", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class QNetAct(C.Structure):
+    _fields_ = [("states", C.c_void_p), ("row_stride", C.c_int64), ("seat_idx", C.c_void_p), ("q_seat", C.c_int32), ("epsilon", C.c_float),
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("table_id0", C.c_uint64), ("terminated", C.c_void_p), ("row_mask_out", C.c_void_p),
+                ("select_scratch", C.c_void_p), ("select_words", C.c_int64)]
+
+
 class QTable(C.Structure):
     _fields_ = [("entries", C.c_void_p), ("capacity", C.c_uint64), ("region_slots", C.c_uint64)]
 
@@ -124,6 +130,7 @@ SYMBOLS = {
     "pulse_comm_all_reduce_i64": (C.c_int, [_P, _P, _P, _I32, _P]),
     "pulse_comm_destroy": (C.c_int, [_P]),
     "pulse_poker_ablate": (C.c_int, [_P, _U32, _P, _P, _U64, _U64, _P]),
+    "pulse_poker_act_policy_step": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P]),
     "pulse_calib_stream": (C.c_int, [_P, _U64, _I32, _P]),
     "pulse_poker_stats": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
     "pulse_poker_hand_metrics": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _P, _P, _P]),

@@ -17,9 +17,11 @@
 // per chunk, every step still stores its observation / reward / done flag / action (ping-pong buffers, exactly what
 // n single launches leave behind), and the changed state words are written once at the end.  The 130 MB hand-rank
 // table is only touched when a poked state misses the evaluation cache the reset kernel fills.
+#include <algorithm>
 #include <type_traits>
 
 #include "poker_device.h"
+#include "qnet_device.h"
 
 using namespace pulse_dev;
 
@@ -125,27 +127,40 @@ template <int N_> struct alignas(4) SeatCells { int32_t v[N_]; };
 // workgroup barrier is involved.
 // MULTI: ca.n_steps steps in one launch (fused policy only); step i writes observation / done flag / reward into
 // the even (i even) or odd buffers, as n single launches on the two ping-pong views would.
-template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, int MULTI>
-__global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
-                                                           const int32_t* __restrict__ actor_idx_in,
-                                                           float* __restrict__ rewards, const PolicyArgs pa, const ChunkArgs ca) {
+// ACT (the learner in the loop): the workgroup -- 256 threads, 128 tables at two lanes each -- first picks
+// the learner's actions for its own window of tables (pulse_qnet::act_window, the body of the stand-alone act launch: masks,
+// row lists for the training launch, forward on the matrix cores, argmax / epsilon draw) and then steps those tables: act ->
+// env step has no grid-wide dependence, so the two launches of the trainer's step are one, and the tables' state is already
+// on its way from HBM while the forward runs.  `qa` = the act launch's arguments (ACT only).
+template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, int MULTI, bool ACT>
+__device__ __forceinline__ void poker_step_body(const PulsePokerView& v, int64_t* __restrict__ actions, const int32_t* __restrict__ actor_idx_in,
+                                                float* __restrict__ rewards, const PolicyArgs& pa, const ChunkArgs& ca, const pulse_qnet::QNetArgs* qa) {
     static_assert((LPT == 4 && (SPL == 3 || SPL == 4)) || (LPT == 2 && (SPL == 5 || SPL == 8)), "lanes per table x seats per lane: 4x3, 4x4, 2x5, 2x8");
     constexpr int TPW = 64 / LPT;                                        // tables per wavefront
+    constexpr int BLK = ACT ? 256 : kStepBlock;                          // threads per workgroup
     static_assert(!MULTI || (POLICY && PH == PULSE_PH_STEP), "a chunk is fused policy + full step");
+    static_assert(!ACT || (MULTI == 1 && LPT == 2), "the act + step launch is a one-step chunk at two lanes per table");
     extern __shared__ int4 smem4[];
     if (POLICY && pa.carry_n > 0 && blockIdx.x == 0) {
         // The stop rule's previous check point: workgroup 0 sums its per-wavefront counts and publishes the total to
         // the host BEFORE its own tables.  (A separate last workgroup did this in the first version; at 65,536 tables
         // the grid fills the chip exactly, so that workgroup only got a slot when the first one retired and the host
         // learned the count ~35 us later than it could -- too late to keep the queue fed at an episode boundary.)
-        sum_and_publish<kStepBlock>(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
-        if (pa.carry2_n > 0) { __syncthreads(); sum_and_publish<kStepBlock>(pa.carry2_partials, pa.carry2_n, nullptr, pa.carry2_host, pa.carry2_seq); }
+        sum_and_publish<BLK>(pa.carry_partials, pa.carry_n, nullptr, pa.carry_host, pa.carry_seq);
+        if (pa.carry2_n > 0) { __syncthreads(); sum_and_publish<BLK>(pa.carry2_partials, pa.carry2_n, nullptr, pa.carry2_host, pa.carry2_seq); }
     }
-    const int gt = blockIdx.x * kStepBlock + threadIdx.x;
+    if (ACT) {
+        // the learner's actions of this workgroup's 128 tables first (the act window owns the workgroup's whole LDS block; the
+        // step's staging reuses it behind the barrier).  Measured: with the step's state loads issued BEFORE the forward -- in
+        // flight underneath it -- the kernel needs 256 registers and spills (42.6 us against 22.7 + 15.2 for the two launches).
+        pulse_qnet::act_window<true, 128, 5>(*qa, reinterpret_cast<float*>(smem4), (int)blockIdx.x);
+        __syncthreads();
+    }
+    const int gt = blockIdx.x * BLK + threadIdx.x;
     const int t = gt / LPT;
     const int j_lane = gt % LPT;
     const int j = j_lane;
-    if (t >= v.n_games) return;   // the lanes of a table leave together
+    if (!ACT && t >= v.n_games) return;   // the lanes of a table leave together (ACT: the host launches whole windows only -- every thread meets the barriers)
     STAMP(0);
     const int P = v.n_players, A = v.active_players;
     const int32_t* __restrict__ hr = v.hand_ranks;
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
             __hip_atomic_store(pa.verdict_dev + (threadIdx.x & 63) * kVerdictStride, (pa.verdict_id << 8) | (long long)flags, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        const long long* mine = pa.verdict_dev + (((blockIdx.x * kStepBlock + threadIdx.x) >> 6) & 63) * kVerdictStride;
+        const long long* mine = pa.verdict_dev + (((blockIdx.x * BLK + threadIdx.x) >> 6) & 63) * kVerdictStride;
         const long long t0 = wall_clock64();
         long long w;
         for (;;) {
@@ -713,7 +728,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int n4 = TPW / 4 * v.obs_size;                             // int4 per wavefront block
-                const int tw0 = (int)((blockIdx.x * kStepBlock + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
+                const int tw0 = (int)((blockIdx.x * BLK + threadIdx.x) >> 6) * TPW;  // first table of this wavefront
                 const uint32_t blk0 = __umul24((uint32_t)tw0, (uint32_t)v.obs_size) * 4u;      // byte offset of the wavefront's block
                 const int4* src = reinterpret_cast<const int4*>(l_obs);
                 constexpr int kBursts = 5;          // two-lane chunk, 40 columns: 32 rows x 160 B = five 1-KiB bursts
@@ -745,7 +760,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
             StepKernargsPtr ka = (StepKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             const int c = __popcll(__ballot(done && j == 0));
-            if ((threadIdx.x & 63) == 0) stg(ka->pa.wave_done_mid, (uint32_t)(blockIdx.x * (kStepBlock / 64) + (threadIdx.x >> 6)) * 4u, (uint32_t)c);
+            if ((threadIdx.x & 63) == 0) stg(ka->pa.wave_done_mid, (uint32_t)(blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)) * 4u, (uint32_t)c);
         }
         if (MULTI) {
             float* fo = obs_dst; obs_dst = obs_nxt; obs_nxt = fo;
@@ -810,7 +825,7 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
         // tables are done -- a plain store, summed on a side stream (atomics onto shared counters cost this launch
         // as much as the separate counting kernel they would replace)
         const int c = __popcll(__ballot(done && j == 0));
-        if ((threadIdx.x & 63) == 0) pa.wave_done[blockIdx.x * (kStepBlock / 64) + (threadIdx.x >> 6)] = (uint32_t)c;
+        if ((threadIdx.x & 63) == 0) pa.wave_done[blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)] = (uint32_t)c;
     }
     STAMP(10);  // state stores issued
 #if PULSE_STAMPS
@@ -822,6 +837,22 @@ __global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kerne
 #undef ROW_OFF
 #undef SEAT
 #undef VS
+}
+
+template <uint32_t PH, bool POLICY, int LPT, int SPL, bool WOBS, int MULTI>
+__global__ __launch_bounds__(kStepBlock, LPT == 4 ? 4 : 2) void poker_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
+                                                           const int32_t* __restrict__ actor_idx_in,
+                                                           float* __restrict__ rewards, const PolicyArgs pa, const ChunkArgs ca) {
+    poker_step_body<PH, POLICY, LPT, SPL, WOBS, MULTI, false>(v, actions, actor_idx_in, rewards, pa, ca, nullptr);
+}
+
+// the learner's action selection + scripted opponents + env step of 128 tables per workgroup (the body's ACT form); the
+// leading arguments are the step kernel's (the body re-reads some of them from the kernel-argument segment by position)
+template <bool WOBS>
+__global__ __launch_bounds__(256, 2) void poker_act_step_kernel(const PulsePokerView v, int64_t* __restrict__ actions,
+                                                                const int32_t* __restrict__ actor_idx_in, float* __restrict__ rewards,
+                                                                const PolicyArgs pa, const ChunkArgs ca, const pulse_qnet::QNetArgs qa) {
+    poker_step_body<PULSE_PH_STEP, true, 2, 5, WOBS, 1, true>(v, actions, actor_idx_in, rewards, pa, ca, &qa);
 }
 
 // ---------------------------------------------------------------- host side
@@ -1093,6 +1124,55 @@ int pulse_poker_rollout(const PulsePokerView* v_even, const PulsePokerView* v_od
     }
     if (timed) { tm->open_launches = chunk ? 1 : n_steps; tm->open_steps = n_steps; timer_end(tm, st); }
     if (int rc = pulse::finish_launch("pulse_poker_rollout")) return rc;
+    if (rule) return pulse::stoprule_commit(rule, n_waves, st);
+    return 0;
+}
+
+/* The trainer's step with the learner in it, first half, as ONE launch: pulse_qnet_act_select on the
+ * observation `act->states` followed by pulse_poker_policy_step on `v` -- same results, word for word (the workgroup that
+ * picks the actions of a window of 128 tables steps those tables itself). */
+int pulse_poker_act_policy_step(const PulsePokerView* v, const uint8_t* agent_types, uint64_t seed, uint64_t step_counter, uint64_t table_id0,
+                                int64_t* actions, float* rewards, const PulseQNet* net, const PulseQNetAct* act, void* stoprule, void* stream) {
+    if (int rc = pulse::check_view(v, "pulse_poker_act_policy_step")) return rc;
+    if (!actions || !rewards || !agent_types || !net || !act) return pulse::fail(PULSE_EINVAL, "pulse_poker_act_policy_step: null argument");
+    if (v->n_games == 0) return 0;
+    const int n = v->n_games;
+    if (n % 128 != 0 || v->max_players > 10 || (v->flags & PULSE_VIEW_FOUR_LANES))
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_act_policy_step: needs a multiple of 128 tables of at most 10 seats (use pulse_qnet_act_select + pulse_poker_policy_step)");
+    if (net->state_dim < 13 || net->state_dim > 40 || net->state_dim % 8 != 0 || net->n_actions < 1 || net->n_actions > 32 || act->row_stride % 4 != 0 ||
+        act->row_stride < net->state_dim || ((uintptr_t)act->states & 15u) || ((uintptr_t)net->w1 & 15u) || ((uintptr_t)net->w2 & 15u) || ((uintptr_t)net->w3 & 15u) ||
+        ((uintptr_t)net->w4 & 15u) || ((uintptr_t)net->w5 & 15u))
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_act_policy_step: needs 16-byte aligned fp32 rows of 16..40 inputs (a multiple of 8) and aligned weights");
+    if (!net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3 || !net->w4 || !net->b4 || !net->w5 || !net->b5 || !act->states || !act->seat_idx || !act->row_mask_out)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_act_policy_step: null weight / state / seat_idx / row_mask_out pointer");
+    if (!act->select_scratch || act->select_words < (int64_t)((n + 255) / 256) * 259 + 512)
+        return pulse::fail(PULSE_EINVAL, "pulse_poker_act_policy_step: select_scratch must hold 259 words per 256 rows + 512");
+    hipStream_t st = (hipStream_t)stream;
+    pulse_qnet::QNetArgs qa{};
+    qa.net = *net; qa.states = act->states; qa.row_stride = act->row_stride; qa.n_rows = n; qa.seat_idx = act->seat_idx; qa.q_seat = act->q_seat;
+    qa.epsilon = act->epsilon; qa.seed = act->seed; qa.step = act->step; qa.table_id0 = act->table_id0; qa.actions = actions; qa.q_out = nullptr;
+    qa.terminated = act->terminated; qa.row_mask_out = act->row_mask_out;
+    qa.tsel_rows = act->select_scratch; qa.tsel_counts = act->select_scratch + (size_t)((n + 255) / 256) * 256;
+    PulseStopRule* rule = static_cast<PulseStopRule*>(stoprule);
+    const int n_waves = n * 2 / 64;
+    uint32_t* wave_done = nullptr;
+    pulse::StopRuleCarry carry{nullptr, 0, nullptr, 0};
+    if (rule) if (int rc = pulse::stoprule_claim(rule, n_waves, &wave_done, &carry)) return rc;
+    const PolicyArgs pa{pulse::pack_types(agent_types, v->n_players), seed, step_counter, table_id0, wave_done, carry.partials, carry.n, carry.host, carry.seq};
+    const ChunkArgs ca{v->obs, rewards, 1};
+    const bool wobs = obs_staging(*v, v->obs, 2);
+    const size_t lds = std::max(pulse_qnet::kActLdsBytes, sizeof(int32_t) * 4 * (size_t)chunk_lds_dwords(v->obs_size, 10, 32, false));
+    const void* fn = wobs ? reinterpret_cast<const void*>(&poker_act_step_kernel<true>) : reinterpret_cast<const void*>(&poker_act_step_kernel<false>);
+    static size_t raised[2] = {0, 0};
+    if (raised[wobs ? 1 : 0] < lds) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_poker_act_policy_step: LDS size attribute");
+        raised[wobs ? 1 : 0] = lds;
+    }
+    const dim3 grid((unsigned)(n / 128)), block(256);
+    if (wobs) hipLaunchKernelGGL(poker_act_step_kernel<true>, grid, block, lds, st, *v, actions, (const int32_t*)nullptr, rewards, pa, ca, qa);
+    else hipLaunchKernelGGL(poker_act_step_kernel<false>, grid, block, lds, st, *v, actions, (const int32_t*)nullptr, rewards, pa, ca, qa);
+    if (int rc = pulse::finish_launch("pulse_poker_act_policy_step")) return rc;
     if (rule) return pulse::stoprule_commit(rule, n_waves, st);
     return 0;
 }

@@ -154,6 +154,7 @@ class PokerGPU(_EnvBase):
         self._pp = 0
         self._views = [None, None]
         self._types_cache = {}
+        self._act_struct = None                      # PulseQNetAct of act_policy_step (filled per call)
         object.__setattr__(self, "_obs_alt", None)
         object.__setattr__(self, "_obs_bufs", None)
 
@@ -392,6 +393,55 @@ class PokerGPU(_EnvBase):
             _native.check(self._lib.pulse_poker_policy_step(C.byref(v), types, self.seed & (2**64 - 1), int(step_counter),
                                                             self.table_id0, actions.data_ptr(), rewards.data_ptr(),
                                                             self._stream()), "pulse_poker_policy_step")
+        pp = 1 - self._pp
+        object.__setattr__(self, "_pp", pp)
+        object.__setattr__(self, "is_done", self._done_bufs[pp])
+        object.__setattr__(self, "obs", self._obs_bufs[pp])
+        return self.obs, rewards, self.is_done, self.is_truncated, self.get_info()
+
+    def act_policy_step(self, learner, q_seat, agent_types, actions, step_counter, states, seat_idx, terminated, row_mask_out, stop_rule=None):
+        """`learner.act_into(states, seat_idx, q_seat, actions, step_counter=step_counter, terminated=terminated,
+        row_mask_out=row_mask_out, select_for_training=True)` followed by `policy_step(agent_types, actions, step_counter)` as
+        ONE launch (pulse_poker_act_policy_step: the workgroup that picks the learner's actions of a window of 128 tables steps
+        those tables itself) -- the same results word for word.  `states` must not be the buffer this step writes its
+        observation into (double_buffer_obs).  `stop_rule`: the done tables after the step are counted for it by the launch
+        (one check point, as rollout(..., stop_rule=)).  Falls back to the two calls where the fused launch does not apply
+        (a table count that is no multiple of 128, more than ten seats, rows the kernel's 16-byte loads cannot take)."""
+        actions = self._actions(actions)
+        n = self.n_games
+        fits = (n % 128 == 0 and self.max_players <= 10 and not self.chunk_four_lanes and self.double_buffer_obs and states.is_cuda
+                and states.dtype == torch.float32 and states.dim() == 2 and states.stride(1) == 1 and states.stride(0) % 4 == 0
+                and states.data_ptr() % 16 == 0 and 16 <= learner.state_dim <= 40 and learner.state_dim % 8 == 0
+                and seat_idx.dtype == torch.int32 and seat_idx.is_contiguous() and row_mask_out is not None)
+        if not fits:
+            learner.act_into(states, seat_idx, q_seat, actions, step_counter=step_counter, terminated=terminated, row_mask_out=row_mask_out,
+                             select_for_training=True)
+            out = self.policy_step(agent_types, actions, step_counter)
+            if stop_rule is not None:
+                stop_rule.submit(terminated | out[2] if terminated is not None else out[2])
+            return out
+        key = tuple(int(x) for x in agent_types)
+        types = self._types_cache.get(key)
+        if types is None:
+            if len(key) != self.n_players:
+                raise ValueError(f"agent_types must have {self.n_players} entries, got {len(key)}")
+            types = self._types_cache[key] = (C.c_uint8 * self.n_players)(*key)
+        v = self._view()
+        if v.obs == states.data_ptr():
+            raise ValueError("act_policy_step: `states` is the buffer this step writes its observation into")
+        rewards = self._rewards[self._pp]
+        net, scratch = learner.begin_fused_act(states, row_mask_out, n)
+        act = self._act_struct
+        if act is None:
+            act = self._act_struct = _native.QNetAct()
+        act.states, act.row_stride, act.seat_idx, act.q_seat = states.data_ptr(), states.stride(0), seat_idx.data_ptr(), int(q_seat)
+        act.epsilon, act.seed, act.step, act.table_id0 = float(learner.epsilon), learner.seed & (2**64 - 1), int(step_counter), learner.table_id0
+        act.terminated = None if terminated is None else terminated.data_ptr()
+        act.row_mask_out, act.select_scratch, act.select_words = row_mask_out.data_ptr(), scratch.data_ptr(), scratch.numel()
+        with self._on_device():
+            _native.check(self._lib.pulse_poker_act_policy_step(
+                C.byref(v), types, self.seed & (2**64 - 1), int(step_counter), self.table_id0, actions.data_ptr(), rewards.data_ptr(),
+                C.byref(net), C.byref(act), None if stop_rule is None else stop_rule.handle, self._stream()), "pulse_poker_act_policy_step")
         pp = 1 - self._pp
         object.__setattr__(self, "_pp", pp)
         object.__setattr__(self, "is_done", self._done_bufs[pp])

@@ -175,6 +175,17 @@ class PokerQNetwork(nn.Module):
                                                    _native.current_stream(states.device)), "pulse_qnet_act")
         return actions
 
+    def begin_fused_act(self, states, row_mask_out, n):
+        """The host side of act_into(select_for_training=True) for a launch that does the acting itself
+        (PokerGPU.act_policy_step): epsilon decay, call count, the row lists' scratch, and the note that the next
+        train_step_native on these states / this mask finds its row lists written.  Returns (network struct, scratch)."""
+        self._decay_epsilon()
+        self._calls += 1
+        self._native_state(n)
+        scratch = self._native["select"]
+        self._act_selected = (states.data_ptr(), states.stride(0), row_mask_out.data_ptr(), n)
+        return self._net_struct(self.network), scratch
+
     # ------------------------------------------------------------------ native learning (csrc/qnet.hip)
     def _flatten(self):
         flats = []

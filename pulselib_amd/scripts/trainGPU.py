@@ -92,7 +92,7 @@ def train_agent(env, agents, agent_types, episodes, n_games, device, results_dir
 
 def train_agent_fused(env, agents, agent_types, episodes, n_games, device, results_dir=None, config=None, plotter=None,
                       benchmarker=None, max_episode_steps=None, reduce_stats=True, stop_rule="lagged", host_seed=0,
-                      step_hook=None, learner="native", hand_metrics=None, prefixed_decks=None):
+                      step_hook=None, learner="native", hand_metrics=None, prefixed_decks=None, fuse_act_step=False):
     """train_agent with nothing in the step waiting on the host: the loop contract above (rotation, masks evaluated
     before `terminated |= dones`, stop cadence, step accounting) on four launches-groups per step --
       learner's actions (pulse_qnet_act, masked by seat) -> scripted opponents + env step (pulse_poker_policy_step) ->
@@ -122,6 +122,9 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     if stop_rule == "steps" and max_episode_steps is None:
         raise ValueError("stop_rule='steps' needs max_episode_steps")
     done_count = LaggedDoneCount(device, n_games, TERMINATION_THRESHOLD, lag=0 if stop_rule == "sync" else 1)
+    # the done tables of a check point are counted by the step's own launch where that launch takes the rule (act_policy_step)
+    fused_count = native and stop_rule != "steps" and hasattr(env, "act_policy_step") and done_count.handle is not None and done_count.exchange != "host"
+    fuse_act_step = bool(fuse_act_step) and native and hasattr(env, "act_policy_step")
     actions = torch.zeros(n_games, dtype=torch.long, device=device)
     # the env alternates two observation buffers from here on: the tensor a step returned is still intact while the
     # next step runs, so the pre-step observation the learner needs is simply the previous `state` (no copy per step)
@@ -161,9 +164,20 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
                 # active_games = q_mask & ~terminated (trainGPU.py:85) comes out of the act launch, and so do the lists of the
                 # rows the training launch will take (it trains on this very observation); `terminated |= dones` (:86) and
                 # the episode reward (:96) ride on the training launches
-                q_agent.act_into(state_before, seat_idx, q_seat, actions, step_counter=global_step, terminated=terminated,
-                                 row_mask_out=active_games, select_for_training=True)
-                next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
+                # every CHECK_INTERVAL-th step the step's launch also counts the done tables for the stop rule (no launch of its own)
+                check = fused_count and idx % CHECK_INTERVAL == 0
+                if fuse_act_step:
+                    # ... the act launch IS the env step's launch (PokerGPU.act_policy_step: the workgroup that picks the actions
+                    # of 128 tables steps them itself) -- measured no faster than the two launches: opt-in
+                    next_state, rewards, dones, _, info = env.act_policy_step(q_agent, q_seat, native_seats, actions, global_step, state_before,
+                                                                              seat_idx, terminated, active_games, stop_rule=done_count if check else None)
+                else:
+                    q_agent.act_into(state_before, seat_idx, q_seat, actions, step_counter=global_step, terminated=terminated,
+                                     row_mask_out=active_games, select_for_training=True)
+                    if check:
+                        next_state, rewards, dones, _, info = env.rollout(native_seats, actions, 1, global_step, stop_rule=done_count)
+                    else:
+                        next_state, rewards, dones, _, info = env.policy_step(native_seats, actions, global_step)
                 if hand_metrics is not None:
                     hand_metrics.update(env, dones, terminated)                       # before terminated |= dones
                 q_agent.train_step_native(state_before, actions, rewards, next_state, dones, active_games, step_counter=global_step,
@@ -182,7 +196,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
             state = next_state
             global_step += 1
             if idx % CHECK_INTERVAL == 0 and stop_rule != "steps":                    # :27-33 cadence
-                done_count.submit(terminated)
+                if not fused_count:                                                   # (else: counted by the step's launch -- the env's done
+                    done_count.submit(terminated)                                     #  flags ARE `terminated`: they never clear inside an episode)
                 if done_count.over():                                                 # the same verdict on every rank
                     break
             idx += 1

@@ -590,3 +590,85 @@ def test_four_and_eight_wavefront_training_kernels_agree(g, tmp_path):
         out[waves] = np.load(path)
     assert out["4"][-4] == out["8"][-4] > 0                                  # rows trained on
     np.testing.assert_allclose(out["4"][:-4], out["8"][:-4], rtol=0, atol=2e-7)     # lr = 2e-4: a step moves a weight by <= 2e-4
+
+
+@pytest.mark.parametrize("N", [4096, 65536])
+def test_act_policy_step_equals_act_then_policy_step(g, N):
+    """ONE launch for the first half of the trainer's step (pulse_poker_act_policy_step: the workgroup that picks the
+    learner's actions of 128 tables steps those tables itself) against the two launches it replaces (act_into with the row
+    lists + policy_step): after every step of three episodes the actions, the trainer's mask, the training launch's row
+    lists, the observation / reward / done buffers and the whole table state are identical word for word, and so is the
+    stop rule's count taken by the launch (scripts/Poker/trainGPU.py:79-86; Player.py:242-253; PokerGPU.py:527-633)."""
+    from pulselib_amd.environments.Poker import PokerGPU
+    from pulselib_amd.stoprule import LaggedDoneCount
+    from tests.helpers import INT_KEYS
+    dev = torch.device(DEV)
+    kw = dict(n_players=10, max_players=10, n_games=N, starting_bbs=100, max_bbs=1000, w1=.5, w2=.3, K=100, alpha=50, seed=99, table_id0=1000)
+    envs = [PokerGPU(device=dev, agents=[], **kw) for _ in range(2)]
+    qs = [_qnet(g, "s40", seed=12, table_id0=1000) for _ in range(2)]
+    for e, q in zip(envs, qs):
+        e.double_buffer_obs = True
+        q.epsilon, q.epsilon_end = 0.2, 0.2
+    rules = [LaggedDoneCount(dev, N, 0.8, lag=0) for _ in range(2)]
+    acts = [torch.zeros(N, dtype=torch.long, device=dev) for _ in range(2)]
+    term = [torch.zeros(N, dtype=torch.bool, device=dev) for _ in range(2)]
+    mask = [torch.zeros(N, dtype=torch.bool, device=dev) for _ in range(2)]
+    gstep, acted = 0, 0
+    for ep, (A, q_seat) in enumerate(((10, 3), (6, 0), (3, 2))):
+        types = [3, 1, 2, 4, 5, 3, 1, 2, 4, 5]
+        types[q_seat] = 0                                              # PULSE_AGENT_EXTERNAL: the learner's seat
+        states, infos = [], []
+        for e, r, t in zip(envs, rules, term):
+            st, info = e.reset(options={"active_players": A, "rotation": ep, "q_agent_seat": q_seat})
+            states.append(st); infos.append(info); r.drain(); t.zero_()
+        for i in range(12):
+            check = i % 5 == 0
+            a, b = envs
+            out_a = a.act_policy_step(qs[0], q_seat, types, acts[0], gstep, states[0], infos[0]["seat_idx"], term[0], mask[0],
+                                      stop_rule=rules[0] if check else None)
+            qs[1].act_into(states[1], infos[1]["seat_idx"], q_seat, acts[1], step_counter=gstep, terminated=term[1], row_mask_out=mask[1],
+                           select_for_training=True)
+            out_b = b.policy_step(types, acts[1], gstep)
+            ctx = f"N={N} episode {ep} step {i}"
+            assert torch.equal(acts[0], acts[1]), ctx + " actions"
+            assert torch.equal(mask[0], mask[1]), ctx + " row mask"
+            acted += int(mask[0].sum())
+            W = N // 128
+            sa, sb = qs[0]._native["select"], qs[1]._native["select"]
+            nw256 = (N + 255) // 256
+            ca, cb = sa[nw256 * 256: nw256 * 256 + W], sb[nw256 * 256: nw256 * 256 + W]
+            assert torch.equal(ca, cb), ctx + " row-list lengths"
+            rows_a, rows_b = sa[:N].view(W, 128), sb[:N].view(W, 128)
+            keep = torch.arange(128, device=dev)[None, :] < ca[:, None]
+            assert torch.equal(rows_a[keep], rows_b[keep]), ctx + " row lists"
+            for x, y, name in zip(out_a[:3], out_b[:3], ("obs", "rewards", "dones")):
+                assert torch.equal(x, y), f"{ctx} {name}"
+            for name in INT_KEYS + ("equities", "prev_stacks", "prev_invested", "equity_dirty"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), f"{ctx} {name}"
+            assert a._pp == b._pp
+            if check:
+                rules[1].submit(out_b[2])
+                assert rules[0].counts() == rules[1].counts() and rules[0].counts()[2], ctx + " stop-rule count"
+            for k in range(2):
+                term[k] |= (out_a, out_b)[k][2]
+                states[k] = (out_a, out_b)[k][0]
+                infos[k] = (out_a, out_b)[k][4]
+            gstep += 1
+    assert qs[0].epsilon == qs[1].epsilon and qs[0]._calls == qs[1]._calls and acted > N
+    # the training launch finds the lists the fused launch wrote (no selection launch of its own): identical updates
+    rew = torch.randn(N, device=dev)
+    nxt = states[0]
+    prev = envs[0]._obs_bufs[1 - envs[0]._pp]
+    for k in range(2):
+        e, q = envs[k], qs[k]
+        st_prev = e._obs_bufs[1 - e._pp]
+        if k == 0:
+            e.act_policy_step(q, 2, types, acts[k], gstep, states[k], infos[k]["seat_idx"], term[k], mask[k])
+        else:
+            q.act_into(states[k], infos[k]["seat_idx"], 2, acts[k], step_counter=gstep, terminated=term[k], row_mask_out=mask[k], select_for_training=True)
+            e.policy_step(types, acts[k], gstep)
+        assert q._act_selected is not None
+        q.train_step_native(states[k], acts[k], rew, e.obs, e.is_done, mask[k], step_counter=gstep)
+    np.testing.assert_array_equal(_flat(qs[0].network), _flat(qs[1].network))
+    for r in rules:
+        r.close()

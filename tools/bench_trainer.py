@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--loop", choices=["fused", "reference"], default="fused")
     ap.add_argument("--learner", choices=["native", "torch"], default="native", help="fused loop only")
     ap.add_argument("--max-episode-steps", type=int, default=40)
+    ap.add_argument("--fuse-act-step", action="store_true", help="act + env step as ONE launch (PokerGPU.act_policy_step)")
     args = ap.parse_args()
     from pulselib_amd.environments.Poker import PokerGPU, PokerQNetwork, load_gpu_agents
     from pulselib_amd.environments.Poker.utils import PokerAgentType
@@ -54,6 +55,7 @@ def main():
     kw = dict(max_episode_steps=args.max_episode_steps, reduce_stats=world > 1)
     if args.loop == "fused":
         kw["learner"] = args.learner
+        kw["fuse_act_step"] = args.fuse_act_step
     run(env, agents, types, args.warmup, args.tables, device, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
