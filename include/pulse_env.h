@@ -243,6 +243,10 @@ int pulse_stoprule_create(int32_t n_local, int64_t n_global, double threshold, i
 int pulse_stoprule_submit(void* handle, const uint8_t* flags, int32_t n, void* stream);   /* flags: device uint8[n], != 0 = done */
 int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t* have);
 int pulse_stoprule_decide(void* handle, int32_t* over);
+/* Publishes the newest check point's count NOW (a one-workgroup launch on the stream that wrote its partial counts) instead
+ * of leaving it to the next launch that carries the rule: for a caller whose next such launch is far away (the trainer: every
+ * fifth step), so that the verdict due then finds its count long published and waits for nothing. */
+int pulse_stoprule_publish(void* handle);
 int pulse_stoprule_drain(void* handle);
 int pulse_stoprule_destroy(void* handle);
 /* How the handle exchanges its counts: 0 = local (one process), 1 = RCCL side stream (any communicator, also of one
@@ -466,6 +470,9 @@ typedef struct PulseQNetTrain {
 } PulseQNetTrain;
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions);
 int pulse_qnet_slice_floats(void);
+/* How many reduce + AdamW launches of this process have called their meeting off so far (a count in pinned host memory the
+ * launches add to: reading it waits for nothing; it is behind by the launches still in flight). */
+int64_t pulse_qnet_called_off_meetings(void);
 int pulse_qnet_train_step(const PulseQNetTrain* t, const float* states, int64_t row_stride, const int64_t* actions,
                           const float* rewards, const float* next_states, int64_t next_stride, const uint8_t* dones,
                           const uint8_t* row_mask, int32_t n_rows, uint64_t seed, uint64_t step_counter,

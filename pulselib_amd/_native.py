@@ -115,6 +115,7 @@ SYMBOLS = {
     "pulse_stoprule_counts": (C.c_int, [_P, _P, _P, _P]),
     "pulse_stoprule_decide": (C.c_int, [_P, _P]),
     "pulse_stoprule_drain": (C.c_int, [_P]),
+    "pulse_stoprule_publish": (C.c_int, [_P]),
     "pulse_stoprule_destroy": (C.c_int, [_P]),
     "pulse_stoprule_mode": (C.c_int, [_P]),
     "pulse_stoprule_side_launches": (_I64, [_P]),
@@ -130,6 +131,7 @@ SYMBOLS = {
     "pulse_comm_all_reduce_i64": (C.c_int, [_P, _P, _P, _I32, _P]),
     "pulse_comm_destroy": (C.c_int, [_P]),
     "pulse_poker_ablate": (C.c_int, [_P, _U32, _P, _P, _U64, _U64, _P]),
+    "pulse_qnet_called_off_meetings": (_I64, []),
     "pulse_poker_act_policy_step": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P]),
     "pulse_calib_stream": (C.c_int, [_P, _U64, _I32, _P]),
     "pulse_poker_stats": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P]),

@@ -919,6 +919,8 @@ int pulse_debug_set_qnet_stamp_buffer(unsigned long long* buf) {
 
 int pulse_qnet_slice_floats(void) { return kSlicePitch; }
 
+int64_t pulse_qnet_called_off_meetings(void) { return g_meet_gave_up ? (int64_t)__atomic_load_n(g_meet_gave_up, __ATOMIC_ACQUIRE) : 0; }
+
 int pulse_qnet_param_count(int32_t state_dim, int32_t n_actions) {
     if (state_dim < 1 || n_actions < 1 || n_actions > 32) return pulse::fail(PULSE_EINVAL, "pulse_qnet_param_count: bad dimensions");
     return 128 * state_dim + 128 + 128 * 128 + 128 + 64 * 128 + 64 + 32 * 64 + 32 + 32 * n_actions + n_actions;

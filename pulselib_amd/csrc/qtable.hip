@@ -112,6 +112,7 @@ __device__ __forceinline__ int choose_action(const U4& r, double epsilon, const 
 // plain stores.  (One list with one global counter: a returning atomic per wavefront on ONE address, ~7 ns apiece one after
 // the other -- 28 of the 72 us of a launch while most wavefronts still had a loser, i.e. for the first ~25 steps after a reset.)
 constexpr int kCountMeet = 0;       // count[0..8) / [8..16): the follow-up launch's arrival counters, by parity
+constexpr int kCountAny = 16;       // count[16 + parity]: != 0 iff some workgroup of the launch deferred something (the follow-up launch's early exit)
 constexpr int kCountWg = 64;        // count[64 + parity * W + w]: deferred transitions of workgroup w (W = ceil(n / 256))
 struct Deferred {                 // per-launch scratch, owned by the caller (PulseQTableScratch)
     unsigned int* count;          // [64 + 2 W], see above
@@ -169,7 +170,11 @@ __device__ __forceinline__ void apply_update(Entry* table, bool live, long long 
 __device__ __forceinline__ void finish_deferred(const Deferred& d, unsigned int* wg_n) {
     if (!d.count) return;
     __syncthreads();
-    if (threadIdx.x == 0) d.count[kCountWg + d.parity * d.n_wg + blockIdx.x] = *wg_n;
+    if (threadIdx.x == 0) {
+        const unsigned int n = *wg_n;
+        d.count[kCountWg + d.parity * d.n_wg + blockIdx.x] = n;
+        if (n) atomicOr(d.count + kCountAny + d.parity, 1u);          // (no return value: pipelined; in the steady state few workgroups get here)
+    }
 }
 
 // The deferred transitions of a launch, in ONE follow-up launch of kDeferBlocks workgroups: (1) every transition finds (or
@@ -184,6 +189,8 @@ __global__ __launch_bounds__(kBlock) void qtable_defer_kernel(Entry* table, Defe
     // the segments' first item numbers (exclusive prefix sum of their lengths; every workgroup computes it for itself): item i of
     // the launch's list = slot 256 w + (i - seg_start[w]) for the segment w that holds it -- the items are dealt to the threads
     // densely (a thread per segment slot would leave most lanes idle for sixteen dependent rounds: 17 -> 57 us when tried)
+    if (blockIdx.x == 0 && threadIdx.x < 9) d.count[threadIdx.x < 8 ? kCountMeet + 8 * (d.parity ^ 1) + threadIdx.x : kCountAny + (d.parity ^ 1)] = 0u;   // the next launch's meeting point and flag
+    if (d.count[kCountAny + d.parity] == 0u) return;                          // nothing was deferred (boards spread over distinct states: the usual case)
     __shared__ unsigned int seg_start[4097];
     __shared__ unsigned int wave_tot[kBlock / 64];
     const unsigned int* lens = d.count + kCountWg + d.parity * d.n_wg;
@@ -198,7 +205,6 @@ __global__ __launch_bounds__(kBlock) void qtable_defer_kernel(Entry* table, Defe
     unsigned int incl = mine;                                                   // inclusive scan over the workgroup's threads
     for (int m = 1; m < 64; m <<= 1) { const unsigned int up = (unsigned int)__shfl_up((int)incl, m); if ((int)(threadIdx.x & 63) >= m) incl += up; }
     if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
-    if (blockIdx.x == 0 && threadIdx.x < 8) d.count[kCountMeet + 8 * (d.parity ^ 1) + threadIdx.x] = 0u;      // the next launch's meeting point
     __syncthreads();
     unsigned int before = 0, n = 0;
     for (int k = 0; k < kBlock / 64; ++k) { if (k < (int)(threadIdx.x >> 6)) before += wave_tot[k]; n += wave_tot[k]; }

@@ -601,6 +601,13 @@ int pulse_stoprule_counts(void* handle, int64_t* local, int64_t* global, int32_t
     return 0;
 }
 
+int pulse_stoprule_publish(void* handle) {
+    PulseStopRule* h = static_cast<PulseStopRule*>(handle);
+    if (!h) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_publish: null argument");
+    if (h->mode == kModeRccl || h->submitted == 0 || h->scheduled >= h->submitted) return 0;     // nothing unpublished (RCCL: the side stream does it)
+    return flush(h, h->submitted - 1);
+}
+
 int pulse_stoprule_decide(void* handle, int32_t* over) {
     PulseStopRule* h = static_cast<PulseStopRule*>(handle);
     if (!over) return pulse::fail(PULSE_EINVAL, "pulse_stoprule_decide: null argument");

@@ -79,6 +79,7 @@ class PokerQNetwork(nn.Module):
         # the reduce launch applies AdamW itself behind a meeting of its workgroups (qnet.hip); True = AdamW as its own launch
         self.separate_apply = False
         self.meet_wait_ticks = 0             # 0: the library's 5 s (ticks of the 100 MHz clock)
+        self._meetings_called_off = int(_native.lib().pulse_qnet_called_off_meetings()) if torch.device(device).type == "cuda" else 0
 
     # ------------------------------------------------------------------ torch side
     def forward(self, states):
@@ -338,12 +339,20 @@ class PokerQNetwork(nn.Module):
             print(f"Step {self.step_count} | Avg Loss: {float(report[1]):.2f} | Epsilon: {self.epsilon:.4f}")
         return report[1]
 
-    def check_native_report(self, report_host=None):
-        """Raises if the last native update was called off inside its launch (report[3] = -1, pulse_env.h: PulseQNetTrain).
-        Reading the report waits for the stream; the trainer calls this at its per-episode read-back."""
+    def check_native_report(self, report_host=None, wait=True):
+        """Raises if a native update was called off inside its launch (report[3] = -1, pulse_env.h: PulseQNetTrain).
+        wait=True reads the last report (waits for the stream); wait=False only looks at the library's count of called-off
+        meetings in pinned host memory (no wait: the trainer's per-episode check; it is behind by the launches in flight)."""
         if self._native is None:
             return
-        rep = self._native["report"].cpu() if report_host is None else report_host
+        if not wait and report_host is None:
+            seen = int(_native.lib().pulse_qnet_called_off_meetings())
+            if seen == self._meetings_called_off:
+                return
+            self._meetings_called_off = seen
+            rep = [0.0, 0.0, 0.0, -1.0]
+        else:
+            rep = self._native["report"].cpu() if report_host is None else report_host
         if float(rep[3]) < 0.0:
             raise RuntimeError("PokerQNetwork: a reduce + AdamW launch could not gather its workgroups (is another process using this GPU?) "
                                "and applied no update; set `separate_apply = True` to run AdamW as a launch of its own")

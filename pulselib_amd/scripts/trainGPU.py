@@ -20,6 +20,7 @@ from ..environments.Poker.utils import PokerAgentType, build_actions, get_rotate
 from ..sharding import EpisodeStats
 
 CHECK_INTERVAL = 5            # trainGPU.py:31
+REPORT_EVERY = 10             # trainGPU.py:110: the reference reports every 10th episode
 TERMINATION_THRESHOLD = 0.8   # trainGPU.py:76
 
 
@@ -138,6 +139,14 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
     stats = EpisodeStats(device)
     total_steps, global_step = 0, 0
     scores, reward_scores, episode_metrics = [], [], []
+    pending = []
+
+    def drain_pending():
+        if pending:
+            host = torch.stack(pending).cpu()                                         # one read-back for all of them
+            reward_scores.extend(float(x) for x in host[:, 1])
+            scores.extend(float(x) for x in host[:, 2])
+            pending.clear()
     start_time = time.time()
     for episode in range(episodes):
         _, rotated_types, q_seat, rotations = get_rotated_agents(agents, agent_types, episode_idx=episode, q_agent_idx=q_agent_idx)
@@ -196,6 +205,8 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
             state = next_state
             global_step += 1
             if idx % CHECK_INTERVAL == 0 and stop_rule != "steps":                    # :27-33 cadence
+                if fused_count:
+                    done_count.publish()                                              # (not with the next check point's launch: the verdict due then must not wait)
                 if not fused_count:                                                   # (else: counted by the step's launch -- the env's done
                     done_count.submit(terminated)                                     #  flags ARE `terminated`: they never clear inside an episode)
                 if done_count.over():                                                 # the same verdict on every rank
@@ -206,15 +217,20 @@ def train_agent_fused(env, agents, agent_types, episodes, n_games, device, resul
         final_stacks = info["stacks"][:, q_seat]
         stats.set(terminated.sum(), episode_reward, (final_stacks - initial_stacks).sum())
         totals = (stats.all_reduce_async() if reduce_stats else stats).wait()
-        host = totals.cpu()                                                           # one read-back per episode
+        # the episode's sums stay on the device; they are read back at the reference's reporting cadence (every REPORT_EVERY-th
+        # episode, trainGPU.py:110) and at the end -- a read-back per episode stalls the queue ~80 us at every boundary
+        pending.append(totals.clone())
         if native:
-            q_agent.check_native_report()                                             # an update called off inside its launch must not pass silently
-        reward_scores.append(float(host[1]))
-        scores.append(float(host[2]))
+            q_agent.check_native_report(wait=False)                                   # an update called off inside its launch must not pass silently
+        if len(pending) >= REPORT_EVERY:
+            drain_pending()
         if hand_metrics is not None:
             episode_metrics.append(hand_metrics.end_episode())
         total_steps += done_count.n_global * idx                                      # :108 (the tables of the whole job: every rank steps in lock step)
 
+    drain_pending()
+    if native:
+        q_agent.check_native_report()
     torch.cuda.synchronize(device)
     done_count.close()
     if double_buffered:

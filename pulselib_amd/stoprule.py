@@ -285,6 +285,12 @@ class LaggedDoneCount:
         _native.check(self._lib.pulse_stoprule_stats(self.handle, out), "pulse_stoprule_stats")
         return {"paired_launches": int(out[0]), "verdict_timeouts": int(out[1]), "pairs": bool(out[2]), "side_stream_check_points": int(out[3])}
 
+    def publish(self) -> None:
+        """Publish the newest check point's count now (pulse_stoprule_publish) instead of with the next launch that carries
+        the rule -- for the trainer, whose next such launch is five steps away."""
+        if self.handle is not None:
+            _native.check(self._lib.pulse_stoprule_publish(self.handle), "pulse_stoprule_publish")
+
     def drain(self) -> None:
         """Episode boundary: the chunks submitted so far decide nothing any more."""
         if self.backend is not None:
