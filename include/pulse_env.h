@@ -425,7 +425,10 @@ int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride
 /* The same (seat_idx and row_mask_out required) for a trainer that will call pulse_qnet_train_step / _grads next with
  * THIS `states` as its states and THIS row_mask_out as its row_mask: the rows that call trains on (row_mask & seat
  * status ACTIVE / ALLIN) are known already, so their lists are written to the trainer's select_scratch here and the
- * training call skips its selection launch -- set PulseQNetTrain.select_from_act = 1 for that call (and only that one). */
+ * training call skips its selection launch -- set PulseQNetTrain.select_from_act = 1 for that call (and only that one).
+ * select_words: at least 259 per 256 rows + 512.  With 517 per 256 rows + 512 and 262,144 rows or more the selection runs
+ * as TWO launches -- the windows only list the learner's rows (in the extra words), a second launch runs them in full
+ * 32-row tiles (a window of 128 candidates holds ~21 of them: a third fewer tiles at 2,000,000 rows) -- same results. */
 int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows,
                           const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
                           uint64_t table_id0, int64_t* actions, const uint8_t* terminated, uint8_t* row_mask_out,

@@ -46,9 +46,61 @@ namespace {
 using namespace pulse_qnet;
 
 template <bool VEC, int WIN, int NK1>
-__global__ __launch_bounds__(256, 2) void qnet_act4_kernel(const QNetArgs a) {
+__global__ __launch_bounds__(256, 3) void qnet_act4_kernel(const QNetArgs a) {
     extern __shared__ float lds[];
     act_window<VEC, WIN, NK1>(a, lds, (int)blockIdx.x);
+}
+
+// The second launch of the two-launch form (large batches): the learner's rows of the whole batch, listed per window by the
+// window launch (a.asel_rows / a.asel_counts), are positions [0, T); persistent workgroups take the FULL 32-row tiles of
+// [0, T) in turn.  A window of 128 candidates holds ~21 of the learner's rows, i.e. a window launch runs its tiles two thirds
+// full: at 2,000,000 tables 15,625 tiles against 10,400 here (522 -> ~370 us), for one more launch (which a small batch,
+// one round of tiles either way, would only pay for).  Per-row results do not depend on the tile a row rides in.
+template <bool VEC, int WIN, int NK1>
+__global__ __launch_bounds__(256, 3) void qnet_act_rows_kernel(const QNetArgs a) {
+    extern __shared__ float lds[];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int n_windows = (a.n_rows + WIN - 1) / WIN, per = (n_windows + 255) / 256;
+    int* chunk = reinterpret_cast<int*>(lds + ActLds::List);     // [256] first position of thread t's windows; [257..260] wavefront totals
+    int T;
+    {
+        int mine = 0;
+        for (int j = 0; j < per; ++j) { const int w = threadIdx.x * per + j; mine += w < n_windows ? a.asel_counts[w] : 0; }
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); incl += lane >= off ? o : 0; }
+        int* wtot = chunk + 257;
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base += i < wv ? wtot[i] : 0;
+        chunk[threadIdx.x] = base + incl - mine;
+        T = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+        __syncthreads();
+    }
+    const int n_tiles = (T + 31) / 32;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int K1 = a.net.state_dim, K1r = (K1 + 7) & ~7;
+    float w1r[NK1][4];
+    load_layer<VEC, NK1>(w1r, a.net, 0, 32 * wv + c, h, 0, K1r);
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        int rowc = -1;
+        const int p = 32 * ti + c;
+        if (p < T) {                                             // its window by bisection of the threads' first positions, then along that thread's windows
+            int t = 0;
+#pragma unroll
+            for (int s = 128; s >= 1; s >>= 1) t += (chunk[t + s] <= p) ? s : 0;
+            int w = t * per, acc = chunk[t], cnt = a.asel_counts[w];
+            while (p >= acc + cnt) { acc += cnt; ++w; cnt = a.asel_counts[w]; }
+            rowc = a.asel_rows[(size_t)w * WIN + (p - acc)];
+        }
+        lds_barrier();                                                        // previous tile's readers are done
+        coop_load_rows<VEC>(lds + ActLds::R0, a.states, a.row_stride, K1, rowc, wv, c, h);
+        const f32x16 qv = group_forward<false, NK1>(w1r, a.net, lds + ActLds::R0, lds + ActLds::R1, lds + ActLds::R0, lds + ActLds::R1, lds + ActLds::R0,
+                                                    nullptr, nullptr, nullptr, nullptr, lds + ActLds::P, wv, c, h, 0, 0, 0, 0, 1.0f);
+        if (wv == 0) act_tile_finish(a, qv, rowc, h);
+    }
 }
 
 // ================================================================ training step (Player.py:255-294)
@@ -794,6 +846,7 @@ __global__ __launch_bounds__(256) void qnet_adamw_kernel(const AdamArgs a) {
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+constexpr int kActTwoLaunchRows = 262144;       // from here on the masked action selection lists first and runs full tiles second
 
 // The fused reduce + AdamW launch is a meeting of all its workgroups inside one ordinary launch: it is only taken where the
 // device can hold the whole grid at once (asked once per device; a smaller part, e.g. a CPX partition, gets the two-launch
@@ -852,6 +905,20 @@ int launch(const QNetArgs& a, void* stream) {
         void* params[1] = {const_cast<QNetArgs*>(&a)};
         const hipError_t le = hipLaunchKernel(fn, dim3(g4), dim3(256), params, kActLdsBytes, st);
         if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_act launch");
+        if (a.asel_counts) {                                 // two-launch form: the window launch listed the rows, this one runs them in full tiles
+            const void* fns2[3] = {reinterpret_cast<const void*>(&qnet_act_rows_kernel<true, kActWin, 5>),
+                                   reinterpret_cast<const void*>(&qnet_act_rows_kernel<true, kActWin, 8>),
+                                   reinterpret_cast<const void*>(&qnet_act_rows_kernel<false, kActWin, 8>)};
+            static const void* attr_set2[3] = {nullptr, nullptr, nullptr};
+            if (attr_set2[slot] != fns2[slot]) {
+                const hipError_t e2 = hipFuncSetAttribute(fns2[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLdsBytes);
+                if (e2 != hipSuccess) return pulse::fail_hip((int)e2, "pulse_qnet_act: LDS size attribute");
+                attr_set2[slot] = fns2[slot];
+            }
+            const unsigned tiles_at_most = (unsigned)((a.n_rows + 31) / 32);
+            const hipError_t l2 = hipLaunchKernel(fns2[slot], dim3(std::min(tiles_at_most, 768u)), dim3(256), params, kActLdsBytes, st);   // three workgroups per CU
+            if (l2 != hipSuccess) return pulse::fail_hip((int)l2, "pulse_qnet_act (rows) launch");
+        }
     }
     else { if (vec) hipLaunchKernelGGL((qnet_kernel<false, true>), dim3(grid), dim3(64), 0, st, a); else hipLaunchKernelGGL((qnet_kernel<false, false>), dim3(grid), dim3(64), 0, st, a); }
     const hipError_t e = hipGetLastError();
@@ -904,7 +971,14 @@ int act_call(const PulseQNet* net, const float* states, int64_t row_stride, int3
     a.net = *net; a.states = states; a.row_stride = row_stride; a.n_rows = n_rows; a.seat_idx = seat_idx; a.q_seat = q_seat;
     a.epsilon = epsilon; a.seed = seed; a.step = step; a.table_id0 = table_id0; a.actions = actions; a.q_out = q_out;
     a.terminated = terminated; a.row_mask_out = row_mask_out;
-    if (select_scratch) { a.tsel_rows = select_scratch; a.tsel_counts = select_scratch + (size_t)((n_rows + 255) / 256) * 256; }
+    if (select_scratch) {
+        const size_t nw = (size_t)((n_rows + 255) / 256);
+        a.tsel_rows = select_scratch; a.tsel_counts = select_scratch + nw * 256;
+        // large batches, scratch permitting: list the learner's rows per window, then run them in full tiles (qnet_act_rows_kernel)
+        if (n_rows >= kActTwoLaunchRows && select_words >= (int64_t)(nw * 517 + 512) && net->state_dim <= 64) {
+            a.asel_rows = select_scratch + nw * 259 + 512; a.asel_counts = a.asel_rows + nw * 256;
+        }
+    }
     return launch(a, stream);
 }
 }  // namespace

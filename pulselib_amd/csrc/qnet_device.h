@@ -91,6 +91,8 @@ struct QNetArgs {
     float* q_out;                                    // nullptr or fp32[n_rows, n_actions]
     const uint8_t* terminated; uint8_t* row_mask_out; // masked form only: row_mask_out[r] = selected && !terminated[r]
     int32_t* tsel_rows; int32_t* tsel_counts;         // nullptr or the training launch's row lists (windows of kActWin rows)
+    int32_t* asel_rows; int32_t* asel_counts;         // nullptr, or: the two-launch form for large batches -- the window launch only
+                                                      // LISTS the learner's rows here, qnet_act_rows_kernel runs them in full tiles
 };
 
 // The network in eval mode on up to 32 rows: lane (c, h) carries the row at `xr` (`live` false = padding column,
@@ -216,7 +218,13 @@ struct CoopLds {                 // offsets in floats into the dynamic LDS block
                          G1 = EndEval, G2 = G1 + 128 * kLd, G3 = G2 + 128 * kLd, G4 = G3 + 64 * kLd,
                          Da = G4 + 32 * kLd, Db = Da + 128 * kLd, EndTrain = Db + 128 * kLd;
 };
-constexpr size_t kActLdsBytes = (size_t)CoopLds::EndEval * sizeof(float);
+// The act window's own map: one network in eval mode needs no layer's input after the next layer has consumed it, so the five
+// activation buffers are two regions used in turn (x, a_2, a_4 in R0; a_1, a_3 in R1), and one network's exchange space:
+// 47 KB instead of 80 -- three workgroups fit a CU's LDS (the registers, 168 at three wavefronts per SIMD, allow it too).
+struct ActLds {
+    static constexpr int R0 = 0, R1 = R0 + 128 * kLd, P = R1 + 128 * kLd, List = P + 3 * 16 * 64, End = List + 264;
+};
+constexpr size_t kActLdsBytes = (size_t)ActLds::End * sizeof(float);
 constexpr int kActWin = 128;
 constexpr size_t kTrainLdsBytes = (size_t)CoopLds::EndTrain * sizeof(float);
 
@@ -644,8 +652,7 @@ __device__ __forceinline__ f32x16 group_forward(const float (&w1r)[NK1][4], cons
 }
 
 // 256 candidate rows -> ids of the selected ones in List[0..count), count returned to every thread
-__device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, int row) {
-    int* list = reinterpret_cast<int*>(lds + CoopLds::List);
+__device__ __forceinline__ int coop_compact(int* __restrict__ list, bool sel, int row) {
     int* wcount = list + 256;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(sel);
@@ -657,6 +664,29 @@ __device__ __forceinline__ int coop_compact(float* __restrict__ lds, bool sel, i
     if (sel) list[base + __popcll(m & ((1ull << lane) - 1ull))] = row;
     __syncthreads();
     return total;
+}
+
+// what wavefront 0 does with a tile's Q values: optional Q output, first maximal index (torch.argmax), epsilon draw, action
+__device__ __forceinline__ void act_tile_finish(const QNetArgs& a, const f32x16& qv, int rowc, int h) {
+    const int A = a.net.n_actions;
+    const bool live = rowc >= 0;
+    if (a.q_out && live) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int o = rho(r) + 4 * h; if (o < A) a.q_out[(size_t)rowc * A + o] = qv[r]; }
+    }
+    float best = -INFINITY; int arg = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = rho(r) + 4 * h;
+        if (o < A && (qv[r] > best || (qv[r] == best && o < arg) || arg == 0x7fffffff)) { best = qv[r]; arg = o; }
+    }
+    const float ob = __shfl_xor(best, 32); const int oa = __shfl_xor(arg, 32);
+    if (oa != 0x7fffffff && (arg == 0x7fffffff || ob > best || (ob == best && oa < arg))) { best = ob; arg = oa; }
+    if (live && h == 0) {
+        const U4 rnd = philox4x32(a.seed, a.table_id0 + (uint64_t)rowc, a.step);
+        const bool explore = rand_unit(rnd.x) < a.epsilon;                               // Player.py:247
+        a.actions[rowc] = explore ? (int64_t)rand_below(rnd.y, A) : (int64_t)arg;        // :248-250
+    }
 }
 
 // ---- masked action selection, cooperative (pulse_qnet_act with seat_idx) ------------------------------------
@@ -676,10 +706,11 @@ __device__ __forceinline__ void act_window(const QNetArgs& a, float* __restrict_
     QSTAMP(0);
     const int K1 = a.net.state_dim, K1r = (K1 + 7) & ~7;
     float w1r[NK1][4];
-    load_layer<VEC, NK1>(w1r, a.net, 0, 32 * wv + c, h, 0, K1r);           // in flight during the compaction
+    if (!a.asel_counts) load_layer<VEC, NK1>(w1r, a.net, 0, 32 * wv + c, h, 0, K1r);           // in flight during the compaction (not when this launch only lists)
     // The rows the NEXT training launch will use (row_mask_out & seat status ACTIVE / ALLIN, Player.py:258-261) are known
     // here already -- it trains on this observation: their lists are written now and the select launch is not needed.
-    int* tcount = reinterpret_cast<int*>(lds + CoopLds::List) + 260;
+    int* const list_w = reinterpret_cast<int*>(lds + ActLds::List);
+    int* tcount = list_w + 260;
     bool tsel = false; unsigned long long tm = 0ull;
     if (a.tsel_counts) {
         tsel = sel && !(a.terminated && a.terminated[row]);
@@ -687,7 +718,7 @@ __device__ __forceinline__ void act_window(const QNetArgs& a, float* __restrict_
         tm = __ballot(tsel);
         if (lane == 0) tcount[wv] = __popcll(tm);
     }
-    const int count = coop_compact(lds, sel, row);                // (its barriers publish tcount too)
+    const int count = coop_compact(list_w, sel, row);             // (its barriers publish tcount too)
     if (a.tsel_counts) {
         int tbase = 0;
 #pragma unroll
@@ -696,34 +727,20 @@ __device__ __forceinline__ void act_window(const QNetArgs& a, float* __restrict_
         if (threadIdx.x == 0) a.tsel_counts[win] = (tcount[0] + tcount[1]) + (tcount[2] + tcount[3]);
     }
     QSTAMP(1);
-    const int* list = reinterpret_cast<const int*>(lds + CoopLds::List);
-    const int A = a.net.n_actions;
+    const int* list = list_w;
+    if (a.asel_counts) {                                                      // (WIN <= 256 threads: one store per listed row)
+        if ((int)threadIdx.x < count) a.asel_rows[(size_t)win * WIN + threadIdx.x] = list[threadIdx.x];
+        if (threadIdx.x == 0) a.asel_counts[win] = count;
+        return;
+    }
     for (int t0 = 0; t0 < count; t0 += 32) {
         const int rowc = t0 + c < count ? list[t0 + c] : -1;
         lds_barrier();                                                        // previous tile's readers are done
-        coop_load_rows<VEC>(lds + CoopLds::Xs, a.states, a.row_stride, K1, rowc, wv, c, h);
-        const f32x16 qv = group_forward<false, NK1>(w1r, a.net, lds + CoopLds::Xs, lds + CoopLds::A1, lds + CoopLds::A2, lds + CoopLds::A3, lds + CoopLds::A4,
-                                                    nullptr, nullptr, nullptr, nullptr, lds + CoopLds::P, wv, c, h, 0, 0, 0, 0, 1.0f);
-        if (wv == 0) {
-            const bool live = rowc >= 0;
-            if (a.q_out && live) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const int o = rho(r) + 4 * h; if (o < A) a.q_out[(size_t)rowc * A + o] = qv[r]; }
-            }
-            float best = -INFINITY; int arg = 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = rho(r) + 4 * h;
-                if (o < A && (qv[r] > best || (qv[r] == best && o < arg) || arg == 0x7fffffff)) { best = qv[r]; arg = o; }
-            }
-            const float ob = __shfl_xor(best, 32); const int oa = __shfl_xor(arg, 32);
-            if (oa != 0x7fffffff && (arg == 0x7fffffff || ob > best || (ob == best && oa < arg))) { best = ob; arg = oa; }
-            if (live && h == 0) {
-                const U4 rnd = philox4x32(a.seed, a.table_id0 + (uint64_t)rowc, a.step);
-                const bool explore = rand_unit(rnd.x) < a.epsilon;                               // Player.py:247
-                a.actions[rowc] = explore ? (int64_t)rand_below(rnd.y, A) : (int64_t)arg;        // :248-250
-            }
-        }
+        coop_load_rows<VEC>(lds + ActLds::R0, a.states, a.row_stride, K1, rowc, wv, c, h);
+        // (a layer writes the region its input's input was read from: that reading ended behind the barrier between the layers)
+        const f32x16 qv = group_forward<false, NK1>(w1r, a.net, lds + ActLds::R0, lds + ActLds::R1, lds + ActLds::R0, lds + ActLds::R1, lds + ActLds::R0,
+                                                    nullptr, nullptr, nullptr, nullptr, lds + ActLds::P, wv, c, h, 0, 0, 0, 0, 1.0f);
+        if (wv == 0) act_tile_finish(a, qv, rowc, h);
         QSTAMP(7);
     }
     QSTAMP(8);

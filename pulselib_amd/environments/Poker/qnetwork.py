@@ -220,7 +220,7 @@ class PokerQNetwork(nn.Module):
                 "partials": torch.empty(TRAIN_BLOCKS * _native.lib().pulse_qnet_slice_floats(), dtype=torch.float32,
                                         device=dev),                                            # 37 MB at 256 workgroups
             }
-        words = 259 * ((max(int(n_rows), 1 << 16) + 255) // 256) + 512        # the training launch's row lists (pulse_env.h)
+        words = 517 * ((max(int(n_rows), 1 << 16) + 255) // 256) + 512        # the training launch's row lists + the act launch's (pulse_env.h)
         if nat.get("select") is None or nat["select"].numel() < words:
             nat["select"] = torch.empty(words, dtype=torch.int32, device=self._flat.device)
             self._struct_cache.pop("train", None)

@@ -672,3 +672,55 @@ def test_act_policy_step_equals_act_then_policy_step(g, N):
     np.testing.assert_array_equal(_flat(qs[0].network), _flat(qs[1].network))
     for r in rules:
         r.close()
+
+
+def test_two_launch_action_selection_of_large_batches_equals_the_window_form(g):
+    """From 262,144 rows on (and with the larger scratch) pulse_qnet_act_select first lists the learner's rows per window and
+    then runs them in FULL 32-row tiles (qnet_act_rows_kernel) instead of one two-thirds-full tile per window of 128
+    candidates: actions, the trainer's mask and the training launch's row lists must be those of the window form (forced
+    here by handing the same learner the small scratch), row for row (Player.py:242-253; utils.py:113-119)."""
+    n = 262144 + 128 * 5 + 77                                   # ragged: a last window that is not full
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(8)
+    states = torch.from_numpy((rng.standard_normal((n, 40)) * 3).round().astype(np.float32)).to(dev)
+    states[:, 12] = torch.from_numpy(rng.integers(0, 4, n).astype(np.float32)).to(dev)
+    seat = torch.from_numpy(rng.integers(0, 6, n).astype(np.int32)).to(dev)
+    seat[1000:1400] = 2                                          # windows full of the learner's rows: four tiles' worth in one window
+    seat[5000:5300] = 5                                          # ... and windows without any
+    term = torch.from_numpy(rng.random(n) < 0.3).to(dev)
+    out = []
+    for big in (True, False):
+        q = _qnet(g, "s40", seed=31, table_id0=123456)
+        q.epsilon, q.epsilon_end = 0.15, 0.15
+        q._native_state(n)
+        nw = (n + 255) // 256
+        if not big:
+            q._native["select"] = torch.empty(259 * nw + 512, dtype=torch.int32, device=dev)
+            q._struct_cache.pop("train", None)
+        else:
+            assert q._native["select"].numel() >= 517 * nw + 512
+        scratch = q._native["select"]
+        scratch.fill_(-7)
+        acts = torch.full((n,), -1, dtype=torch.long, device=dev)
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        # (act_into would re-create the scratch at its default size: call the entry point the way it does)
+        from pulselib_amd import _native
+        net = q._net_struct(q.network)
+        _native.check(_native.lib().pulse_qnet_act_select(C.byref(net), states.data_ptr(), states.stride(0), n, seat.data_ptr(), 2, float(q.epsilon),
+                                                          q.seed, 4242, q.table_id0, acts.data_ptr(), term.view(torch.uint8).data_ptr(),
+                                                          mask.view(torch.uint8).data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                                          torch.cuda.current_stream().cuda_stream), "pulse_qnet_act_select")
+        torch.cuda.synchronize()
+        W = (n + 127) // 128
+        counts = scratch[nw * 256: nw * 256 + W].clone()
+        rows = scratch[:W * 128].view(W, 128).clone()
+        out.append((acts.clone(), mask.clone(), counts, rows))
+        if big:                                                   # the act lists exist and hold exactly the learner's rows
+            a_counts = scratch[nw * 259 + 512 + nw * 256: nw * 259 + 512 + nw * 256 + W]
+            assert int(a_counts.sum()) == int((seat == 2).sum())
+    (a1, m1, c1, r1), (a2, m2, c2, r2) = out
+    assert torch.equal(a1, a2) and torch.equal(m1, m2) and torch.equal(c1, c2)
+    keep = torch.arange(128, device=dev)[None, :] < c1[:, None]
+    assert torch.equal(r1[keep], r2[keep])
+    mine = seat == 2
+    assert bool((a1[~mine] == -1).all()) and bool(((a1[mine] >= 0) & (a1[mine] < 13)).all()) and int(mine.sum()) > n // 8
