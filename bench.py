@@ -438,15 +438,18 @@ def recorded_traffic(tables, steps_per_launch, active_players):
     the newest committed summary (profiles/rNN/step_kernel_profile*.json: FETCH_SIZE / WRITE_SIZE in separate passes,
     corrected by the dword-stream calibration recorded with them) that matches this workload AND was collected from the
     kernel source this build was compiled from (sha256 over KERNEL_SOURCES recorded at collection time); otherwise None
-    with the reason.  A summary whose mean steps per launch differs by up to 1.5 from this run's (short blocks cut a few
-    launches to one check interval) is scaled by the ratio, and says so.  Returns (bytes or None, source string)."""
+    with the reason.  The summary with the closest mean steps per launch is taken (up to 2.5 away: short blocks cut some
+    launches to one check interval) and quoted AS IT IS, with both launch mixes named: a launch's fabric traffic is its state
+    in and out plus what the caches do not absorb of the per-step outputs, and barely moves with the steps it runs (r04:
+    78.7 MB at 9.97 steps per launch, 77.5 MB at 8.82) -- scaling it by the ratio, as round 3 did, was wrong.
+    Returns (bytes or None, source string)."""
     want_sha = _sha_of_kernel_sources()
     best, best_rank, why = None, None, "no profiles/r*/step_kernel_profile*.json matches this workload"
     for f in sorted((ROOT / "profiles").glob("r*/step_kernel_profile*.json")):
         try:
             d = json.loads(f.read_text())
             have = float(d.get("steps_per_launch_mean", d.get("steps_per_launch", 1)))
-            if int(d.get("tables_per_launch", -1)) != tables or abs(have - steps_per_launch) > 1.5:
+            if int(d.get("tables_per_launch", -1)) != tables or abs(have - steps_per_launch) > 2.5:
                 continue
             if str(d.get("active_players", "sampled")) != str(active_players):
                 continue
@@ -458,9 +461,9 @@ def recorded_traffic(tables, steps_per_launch, active_players):
             if best_rank is not None and rank_of < best_rank:
                 continue
             best_rank = rank_of
-            best, why = float(d["traffic_bytes_per_launch"]) * steps_per_launch / have, rel
+            best, why = float(d["traffic_bytes_per_launch"]), rel
             if abs(have - steps_per_launch) > 0.05:
-                why += f" (scaled from {have:.2f} to {steps_per_launch:.2f} steps per launch)"
+                why += f" (collected at {have:.2f} steps per launch, this run {steps_per_launch:.2f}: not scaled)"
         except Exception:
             pass
     return (best, why) if best is not None else (None, why)

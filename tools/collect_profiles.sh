@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun): rocprofv3 passes behind the numbers bench.py and profiles/ quote.
-#   tools/collect_profiles.sh <round-tag> [parts]      e.g. r03   (parts: poker envs trainer bench rehearsal; default all)
+#   tools/collect_profiles.sh <round-tag> [parts]      e.g. r04   (parts: poker envs trainer harness bench rehearsal; default all)
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never mixed
 # with --stats / trace domains).  Raw output goes to gpurun_out/<tag>/, summaries to profiles/<tag>/.
 # Poker workloads: 65,536 tables (BASELINE config 2, the bench default) and 1,048,576 tables (config 4's total on one GPU),
@@ -8,7 +8,7 @@
 set -e
 T="timeout -k 10 300"      # a profiled bench takes seconds; never let one hang the box
 TAG=${1:-r03}
-PARTS=${2:-"poker envs trainer bench rehearsal"}
+PARTS=${2:-"poker envs trainer harness bench rehearsal"}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -47,6 +47,26 @@ if [[ $PARTS == *trainer* ]]; then
   rm -rf $OUT/trainer
   echo "[collect] $(date +%T) trainer loop"; $T $P --stats -d $OUT/trainer -- python bench.py --inproc --no-cpu-baseline --trainer-loop on --trainer-tables-large 0 --other-envs off --census off --active-players sampled --steps 200 --warmup 40 --min-timed-ms 10 > $OUT/trainer_trace.log 2>&1
   $T python bench.py --inproc --no-cpu-baseline --trainer-loop on --other-envs off --census off --active-players sampled --steps 200 --warmup 40 --min-timed-ms 10 > $OUT/trainer_plain.log 2> $OUT/trainer_plain.err
+fi
+if [[ $PARTS == *trainer* ]]; then
+  # ... and the same loop at the reference's published size, with the SQ counters of its kernels (tools/trainer_profile_at.sh)
+  echo "[collect] $(date +%T) trainer loop at 2,000,000 tables"
+  bash tools/trainer_profile_at.sh 2000000 4 $TAG/trainer_2m counters > $OUT/trainer_2m.log 2>&1 || echo "trainer 2M profile failed"
+  mkdir -p profiles/$TAG
+  cp $OUT/trainer_2m/kernel_stats.csv profiles/$TAG/trainer_kernel_stats_2000000.csv 2>/dev/null
+  cp $OUT/trainer_2m/counters.txt profiles/$TAG/trainer_counters_2000000.txt 2>/dev/null
+  grep '"value"' $OUT/trainer_2m/plain.log > profiles/$TAG/trainer_line_2000000.json 2>/dev/null
+fi
+if [[ $PARTS == *harness* ]]; then
+  # the reference's benchmark harness on the HIP classes (benchmarking/Poker/run.py): the four presets' reports
+  mkdir -p profiles/$TAG
+  for PRE in quick standard stress mi355x; do
+    echo "[collect] $(date +%T) harness preset $PRE"
+    rm -rf $OUT/harness_$PRE
+    $T python -m pulselib_amd.benchmarking --preset $PRE --output-dir $OUT/harness_$PRE > $OUT/harness_$PRE.txt 2> $OUT/harness_$PRE.err || echo "harness $PRE failed"
+    grep -v amdgpu.ids $OUT/harness_$PRE.txt > profiles/$TAG/harness_$PRE.txt
+    f=$(ls $OUT/harness_$PRE/*.json 2>/dev/null | head -1); [ -n "$f" ] && cp $f profiles/$TAG/harness_$PRE.json
+  done
 fi
 if [[ $PARTS == *bench* ]]; then
   echo "[collect] $(date +%T) default bench (the driver's line)"; $T python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
