@@ -78,7 +78,7 @@ def parse_args(argv=None):
                     help="episode cap: the reference's close-on-aggressor rule livelocks tables whose last ACTIVE seat "
                          "keeps calling against all-ins (SURVEY.md A.3), so >20 %% of tables may never finish; its "
                          "published runs average 31-35 steps per episode (results/PokerGPU/runs/run_2..8.yaml)")
-    ap.add_argument("--min-timed-ms", type=float, default=1000.0, help="repeat the K-step block until the blocks sum to this")
+    ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="repeat the K-step block until the blocks sum to this")
     ap.add_argument("--min-episodes", type=int, default=8, help="... and span at least this many episodes")
     ap.add_argument("--max-repeats", type=int, default=20000)
     ap.add_argument("--per-step-launches", action="store_true", help="one launch per step instead of one per chunk (A/B)")
@@ -325,7 +325,7 @@ def cpu_baseline(args):
                      f"cap {args.max_episode_steps} steps/episode)"}
     if args.other_envs != "off":
         from tools.bench_envs import cpu_records
-        out["other_envs"] = cpu_records(seconds_each=3.0)
+        out["other_envs"] = cpu_records(seconds_each=2.0)
     return out
 
 
