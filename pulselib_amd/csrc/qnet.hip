@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, 3) void qnet_act_rows_kernel(const QNetArgs a)
 // Launch 2 (qnet_grad_reduce_kernel) sums the slices into the flat gradient and its squared norm and, on one GPU, applies
 // mean / clip_grad_norm_ / AdamW / target sync to the parameters it holds the sums of (qnet_adamw_kernel: the same as a
 // launch of its own, for data-parallel training where an all-reduce comes between the two).
+constexpr int kMeetUsed = 400;                 // meet[400]: how many of the training launch's workgroups wrote a slice (workgroups 0 .. that - 1)
 struct TrainArgs {
     FlatNet net, tgt;
     float* partials;                          // [gridDim.x][kSlicePitch]: gradient blocks, biases, then {rows, sum td^2, -, used}
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256) void qnet_train_kernel(const TrainArgs a) {
     // full tiles: fewer slices to reduce than with T rows spread over all the workgroups (a tile costs the same with 25 rows
     // as with 32), and every workgroup at most one more tile than any other
     const int n_tiles = (T + 31) / 32;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.meet[kMeetUsed] = (unsigned)min(n_tiles, G);      // workgroups 0 .. n_tiles - 1 hold a gradient slice (the reduce launch sums exactly those)
     for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
         {
             const bool first = !used;
@@ -518,6 +520,7 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
     // full tiles: fewer slices to reduce than with T rows spread over all the workgroups (a tile costs the same with 25 rows
     // as with 32), and every workgroup at most one more tile than any other
     const int n_tiles = (T + 31) / 32;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.meet[kMeetUsed] = (unsigned)min(n_tiles, G);      // workgroups 0 .. n_tiles - 1 hold a gradient slice (the reduce launch sums exactly those)
     for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
         const bool first = !used;
         used = true;
@@ -699,36 +702,22 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (j0 < kSliceStats) {
         const float* p = a.partials + j0;
-        const float* flag = a.partials + kSliceStats + 3;            // 1: the slice's workgroup had a tile (else its blocks are stale)
-        int b = (int)((long long)a.n_blocks * grp / 8);
-        const int end = (int)((long long)a.n_blocks * (grp + 1) / 8);
-        for (; b + 16 <= end; b += 16) {
-            float4 v[16]; float u[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) u[i] = flag[(size_t)(b + i) * pitch];
+        // The slices that hold a gradient are those of workgroups 0 .. used - 1 (the training launch left the count): their
+        // columns are loaded UNCONDITIONALLY, sixteen in flight per thread -- testing every slice's own flag first made each
+        // pass two dependent round trips, and with a remainder loop a launch was eight of them (13.3 -> 11.5 us for 30 MB).
+        // (Prefetching the slices' statistics for the totals below as well made the launch slower, 13.7 us: dropped.)
+        const int used = min(a.n_blocks, (int)a.meet[kMeetUsed]);
+        int b = (int)((long long)used * grp / 8);
+        const int end = (int)((long long)used * (grp + 1) / 8);
+        for (; b < end; b += 16) {
+            float4 v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (u[i] != 0.0f) v[i] = *reinterpret_cast<const float4*>(p + (size_t)(b + i) * pitch);   // (the two halves of a wavefront are on different slices)
+                if (b + i < end) v[i] = *reinterpret_cast<const float4*>(p + (size_t)(b + i) * pitch);   // (the two halves of a wavefront are on different slices)
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
-        }
-        for (; b + 8 <= end; b += 8) {
-            float4 v[8]; float u[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) u[i] = flag[(size_t)(b + i) * pitch];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (u[i] != 0.0f) v[i] = *reinterpret_cast<const float4*>(p + (size_t)(b + i) * pitch);   // (the two halves of a wavefront are on different slices)
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
-        }
-        for (; b < end; ++b) {
-            if (flag[(size_t)b * pitch] == 0.0f) continue;
-            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * pitch); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
     part8[grp][lane] = acc;
