@@ -248,7 +248,7 @@ class EpisodeStatsReducer:
     def _reduce(self, asynchronous):
         import torch.distributed as dist
         if dist.get_backend() == "gloo":             # one-GPU rehearsal: gloo reduces host copies
-            host = self.local.cpu()
+            host = self.local.to("cpu", copy=True)    # (a copy even when the sums already live on the host: the rank's own totals stay its own)
             dist.all_reduce(host)
             self.reduced.copy_(host)
         else:

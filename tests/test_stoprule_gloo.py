@@ -210,3 +210,64 @@ def test_shm_segment_tells_ranks_that_share_a_device():
     finally:
         for h in hs:
             lib.pulse_shm_destroy(h)
+
+
+class _StatsEnv(_FakeEnv):
+    """_FakeEnv + what bench.EpisodeStatsReducer touches of PokerGPU: the cumulative accumulator (here on the CPU; the reset
+    "launch" adds the ended episode's sums to it) and the reward buffers."""
+
+    def __init__(self, rate, log, rank):
+        super().__init__(rate, log)
+        self.rank, self._pp = rank, 0
+        self._rewards = [torch.zeros(N_LOCAL), torch.zeros(N_LOCAL)]
+
+    def new_episode_stats(self):
+        return torch.zeros((4, 2), dtype=torch.float64)
+
+    @staticmethod
+    def episode_stats_totals(acc):
+        return acc.sum(dim=0)
+
+    def reset(self, options=None):
+        stats = (options or {}).get("episode_stats")
+        if stats is not None:                               # the ended episode's sums join the running totals (pulse_poker_reset does this)
+            _, acc = stats
+            acc[self.episode % 4, 0] += 100.0 * (self.rank + 1) + self.episode
+            acc[self.episode % 4, 1] += float(min(1.0, self.rate * self.steps) * N_LOCAL)
+        super().reset(options)
+
+
+def _stats_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        env = _StatsEnv(rate=(0.09, 0.03)[rank], log=[], rank=rank)
+        rule = LaggedDoneCount(torch.device("cpu"), N_LOCAL, 0.8, lag=1, n_global=N_LOCAL * world, backend=HostCounts(1))
+        stats = bench.EpisodeStatsReducer(env, torch.device("cpu"), world)
+        loop = bench.EpisodeLoop(env, rule, actions=None, max_episode_steps=40, on_episode_end=stats)
+        assert loop.run_steps(1000) == 1000
+        ended = loop.episode - 1                             # episodes whose sums have joined the totals (the running one has not)
+        during = stats.collectives
+        totals = stats.totals()
+        out[rank] = {"ended": ended, "during": during, "collectives": stats.collectives, "totals": totals, "local": stats.local.sum(dim=0).tolist()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_episode_statistics_are_all_reduced_every_tenth_episode_and_at_the_end():
+    """bench.py's EpisodeStatsReducer at N > 1: the ranks' CUMULATIVE episode sums cross the ranks at
+    the reference's reporting cadence (every 10th episode, scripts/Poker/trainGPU.py:110) and once more when the totals are
+    asked for -- not at every episode -- and the totals are the sum of the ranks' own accumulators, identical on every rank."""
+    import bench
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_stats_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["ended"] == b["ended"] > 25
+    assert a["during"] == b["during"] == a["ended"] // bench.REPORT_EVERY          # one collective per ten ended episodes ...
+    assert a["collectives"] == b["collectives"] == a["during"] + 1                 # ... and the final one
+    assert a["totals"] == b["totals"]
+    assert abs(a["totals"]["last_step_reward_sum"] - (a["local"][0] + b["local"][0])) < 1e-9
+    assert abs(a["totals"]["tables_done_at_episode_end"] - (a["local"][1] + b["local"][1])) < 1e-9
+    assert a["local"][0] != b["local"][0]                                          # (the ranks' own sums differ: the totals are a real reduction)
