@@ -109,6 +109,21 @@ __device__ __forceinline__ void sort64_in_row(uint32_t (&a)[4], int lane) {
     cx(a[0], a[2]); cx(a[1], a[3]); cx(a[0], a[1]); cx(a[2], a[3]);
 }
 
+// x mod m for the small operands of the reset (seat and button arithmetic, m <= 16): a multiply and a shift with a reciprocal
+// from a table instead of the ~25 vector instructions of a 32-bit division by a run-time divisor -- this kernel is bound by
+// vector-instruction issue.  Anything outside 0..255 (a poked button) takes the general path.
+struct Rcp16Table {
+    uint32_t v[PULSE_MAX_SEATS + 1];
+    constexpr Rcp16Table() : v{} { for (int m = 1; m <= PULSE_MAX_SEATS; ++m) v[m] = 65536u / (uint32_t)m + 1u; }
+};
+__device__ const Rcp16Table kRcp16{};
+__device__ __forceinline__ int mod_small(int x, int m, uint32_t rcp) {
+    if ((uint32_t)x < 256u) return x - (int)(((uint32_t)x * rcp) >> 16) * m;       // exact: x < 256, m <= 16
+    return pymod(x, m);
+}
+__device__ __forceinline__ int wrap_up(int x, int m) { return x >= m ? x - m : x; }     // x mod m for 0 <= x < 2 m
+__device__ __forceinline__ int wrap_down(int x, int m) { return x < 0 ? x + m : x; }    // x mod m for -m <= x < m
+
 #ifndef PULSE_RESET_WIDE
 #define PULSE_RESET_WIDE 1        // 0: the per-wavefront narrow stores of rounds 1-3 (`make reset-narrow`: the A/B twin, tools/reset_ab.sh)
 #endif
@@ -122,7 +137,9 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     const int P = v.n_players, A = v.active_players;
     const bool seat = s < P, inA = s < A;
     const size_t row = (size_t)t * P + s;
+#if !PULSE_RESET_WIDE
     int32_t* dk = o.decks_out + (size_t)t * 52;
+#endif
 
     // decks: prefixed copy (:88-92) or rank-of-random-key shuffle == rand().argsort()+1 (:86).
     // The table's 16 lanes sit in one wavefront, LDS ops of a wavefront retire in order, so the
@@ -153,7 +170,9 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         for (int c = s; c < 52; c += kLanes) deck_s[g][c] = src[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if !PULSE_RESET_WIDE
     for (int c = s; c < 52; c += kLanes) dk[c] = deck_s[g][c];
+#endif
 
     // statistics of the episode that ends here (the caller's per-episode sums, trainGPU.py:96,104), before its flags go
     if (o.stats_out) {
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     // stacks: refill busted / over-max, then torch.roll by `rotation` (:101-110)
     int st = o.starting_bbs;
     if (seat && !o.first) {
-        const int src = pymod(s - o.rotation, P);
+        const int src = wrap_down(s - mod_small(o.rotation, P, kRcp16.v[P]), P);          // pymod(s - rotation, P), s < P
         st = v.stacks[(size_t)t * P + src];
         if (st == 0 || st > o.max_bbs) st = o.starting_bbs;
     }
@@ -193,7 +212,8 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         unsigned long long m = 0;
         uint32_t bad = 0;
         if (inA) { bad = !(card_ok(h0) && card_ok(h1)); m = (1ull << (h0 & 63)) | (1ull << (h1 & 63)); }
-        for (int x = 1; x < kLanes; x <<= 1) { m |= __shfl_xor(m, x, kLanes); bad |= (uint32_t)__shfl_xor((int)bad, x, kLanes); }
+        m = (unsigned long long)row_or((uint32_t)m) | (unsigned long long)row_or((uint32_t)(m >> 32)) << 32;   // over the table's 16 lanes: DPP
+        bad = row_or(bad);
         const bool board_ok = card_ok(f0) && card_ok(f1) && card_ok(f2) && card_ok(f3) && card_ok(f4);
         m |= (1ull << (f0 & 63)) | (1ull << (f1 & 63)) | (1ull << (f2 & 63)) | (1ull << (f3 & 63)) | (1ull << (f4 & 63));
         const bool valid = !bad && board_ok && __popcll(m) == 2 * A + 5;    // 2A+5 distinct cards in 1..52
@@ -203,10 +223,10 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         if (seat && !(valid && inA)) v.pre_hands[row] = 0;
         if (s == 0) v.pre_board[t] = valid ? (int32_t)(pack_board(f0, f1, f2, f3, f4) | kPreBoardValid) : 0;
     }
-    const int button = o.first ? 0 : pymod(v.button[t] + 1, A);                         // :121
+    const int button = o.first ? 0 : mod_small(v.button[t] + 1, A, kRcp16.v[A]);        // :121
     int sb, bb, idx;
-    if (A == 2) { sb = button; bb = pymod(button + 1, A); idx = button; }               // :123-125,:131
-    else { sb = pymod(button + 1, A); bb = pymod(button + 2, A); idx = pymod(bb + 1, A); }
+    if (A == 2) { sb = button; bb = wrap_up(button + 1, A); idx = button; }             // :123-125,:131  (button < A, A >= 2)
+    else { sb = wrap_up(button + 1, A); bb = wrap_up(button + 2, A); idx = wrap_up(bb + 1, A); }
     int bet = 0, inv = 0, status = inA ? PULSE_ACTIVE : PULSE_SITOUT;
     if (s == bb) { st -= 1; bet = 1; inv = 1; status = st == 0 ? PULSE_ALLIN : PULSE_ACTIVE; }   // :188-199
     if (seat) {
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         switch (s) {
         case 0: case 1: case 2: case 3: case 4: hv = -1; break;
         case 5: hv = a_h0; break; case 6: hv = a_h1; break; case 7: hv = 0; break;
-        case 8: hv = pymod(idx - button, A); break; case 9: hv = 1; break; case 10: hv = 1 - a_bet; break;
+        case 8: hv = wrap_down(idx - button, A); break; case 9: hv = 1; break; case 10: hv = 1 - a_bet; break;
         case 11: hv = a_stack; break; default: hv = a_status; break;
         }
         ob[s] = (float)hv;
@@ -268,6 +288,9 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
             v.equity_dirty[tt] = 1; v.prev_stacks[tt] = 0; v.prev_invested[tt] = 0;
         }
         for (int i = e; i < nw * 5; i += kBlock) v.board[t0w * 5 + i] = -1;            // :95
+        const int32_t* deck_flat = &deck_s[0][0];                                      // the workgroup's decks: one contiguous block
+        int32_t* dk = o.decks_out + (size_t)t0w * 52;
+        for (int i = e; i < nw * 52; i += nw * kLanes) dk[i] = deck_flat[i];          // (the threads of tables past the end have left: nw * 16 run)
     }
 #endif
     if (!v.pre_board) return;

@@ -593,12 +593,15 @@ def test_four_and_eight_wavefront_training_kernels_agree(g, tmp_path):
 
 
 @pytest.mark.parametrize("N", [4096, 65536])
-def test_act_policy_step_equals_act_then_policy_step(g, N):
+def test_act_policy_step_equals_act_then_policy_step(g, N, monkeypatch):
     """ONE launch for the first half of the trainer's step (pulse_poker_act_policy_step: the workgroup that picks the
     learner's actions of 128 tables steps those tables itself) against the two launches it replaces (act_into with the row
     lists + policy_step): after every step of three episodes the actions, the trainer's mask, the training launch's row
     lists, the observation / reward / done buffers and the whole table state are identical word for word, and so is the
-    stop rule's count taken by the launch (scripts/Poker/trainGPU.py:79-86; Player.py:242-253; PokerGPU.py:527-633)."""
+    stop rule's count taken by the launch (scripts/Poker/trainGPU.py:79-86; Player.py:242-253; PokerGPU.py:527-633).  (The fused
+    launch runs the network on 32-row tiles; the stand-alone act launch is held to that form here -- its default, four rows per
+    wavefront, sums in another order and may break a near tie of two Q values the other way.)"""
+    monkeypatch.setenv("PULSE_ACT_TILES", "1")
     from pulselib_amd.environments.Poker import PokerGPU
     from pulselib_amd.stoprule import LaggedDoneCount
     from tests.helpers import INT_KEYS
@@ -674,11 +677,13 @@ def test_act_policy_step_equals_act_then_policy_step(g, N):
         r.close()
 
 
-def test_two_launch_action_selection_of_large_batches_equals_the_window_form(g):
-    """From 262,144 rows on (and with the larger scratch) pulse_qnet_act_select first lists the learner's rows per window and
+def test_two_launch_action_selection_of_large_batches_equals_the_window_form(g, monkeypatch):
+    """The 32-row-tile forms of the masked action selection (what shapes outside the four-rows-per-wavefront kernel's run, and
+    PULSE_ACT_TILES=1): from 262,144 rows on (and with the larger scratch) pulse_qnet_act_select first lists the learner's rows per window and
     then runs them in FULL 32-row tiles (qnet_act_rows_kernel) instead of one two-thirds-full tile per window of 128
     candidates: actions, the trainer's mask and the training launch's row lists must be those of the window form (forced
     here by handing the same learner the small scratch), row for row (Player.py:242-253; utils.py:113-119)."""
+    monkeypatch.setenv("PULSE_ACT_TILES", "1")
     n = 262144 + 128 * 5 + 77                                   # ragged: a last window that is not full
     dev = torch.device(DEV)
     rng = np.random.default_rng(8)
@@ -724,3 +729,73 @@ def test_two_launch_action_selection_of_large_batches_equals_the_window_form(g):
     assert torch.equal(r1[keep], r2[keep])
     mine = seat == 2
     assert bool((a1[~mine] == -1).all()) and bool(((a1[mine] >= 0) & (a1[mine] < 13)).all()) and int(mine.sum()) > n // 8
+
+
+@pytest.mark.parametrize("n,case", [(70001, "s40"), (300, "s40"), (5000, "s64")])
+def test_four_rows_per_wavefront_action_selection_equals_the_tile_form(g, n, case, monkeypatch):
+    """pulse_qnet_act_select's default kernel (csrc/qnet_rows4.h: v_mfma_f32_4x4x1 with the A broadcast, four rows per
+    wavefront, the network in LDS) against the cooperative 32-row tiles (PULSE_ACT_TILES=1) on the same inputs: the trainer's
+    mask and the training launch's row lists are identical, the Q rows agree to the order of the sums, and the actions are
+    equal wherever the two best Q values of a row are further apart than that (Player.py:242-253; utils.py:113-119).  Ragged
+    sizes, windows full of the learner's rows (four passes of the 16 wavefronts) and windows without any."""
+    from pulselib_amd import _native
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(n)
+    sd = 40 if case == "s40" else 64
+    states = torch.from_numpy((rng.standard_normal((n, sd)) * 3).round().astype(np.float32)).to(dev)
+    states[:, 12] = torch.from_numpy(rng.integers(0, 4, n).astype(np.float32)).to(dev)
+    seat = torch.from_numpy(rng.integers(0, 6, n).astype(np.int32)).to(dev)
+    if n > 2000:
+        seat[1000:1700] = 2
+        seat[1700:2300] = 5
+    else:
+        seat[:] = 2
+    term = torch.from_numpy(rng.random(n) < 0.3).to(dev)
+    out = []
+    for tiles in (False, True):
+        monkeypatch.setenv("PULSE_ACT_TILES", "1" if tiles else "0")
+        if case == "s64":
+            from pulselib_amd.environments.Poker import PokerQNetwork
+            torch.manual_seed(64)
+            q = PokerQNetwork(None, dev, gamma=.97, update_freq=3, state_dim=64, action_dim=13, learning_rate=1e-3, weight_decay=0.01,
+                              seed=31, table_id0=123456)
+        else:
+            q = _qnet(g, case, seed=31, table_id0=123456)
+        q.epsilon, q.epsilon_end = 0.15, 0.15
+        q._native_state(n)
+        nw = (n + 255) // 256
+        scratch = q._native["select"]
+        scratch.fill_(-7)
+        acts = torch.full((n,), -1, dtype=torch.long, device=dev)
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        net = q._net_struct(q.network)
+        _native.check(_native.lib().pulse_qnet_act_select(C.byref(net), states.data_ptr(), states.stride(0), n, seat.data_ptr(), 2, float(q.epsilon),
+                                                          q.seed, 4242, q.table_id0, acts.data_ptr(), term.view(torch.uint8).data_ptr(),
+                                                          mask.view(torch.uint8).data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                                          torch.cuda.current_stream().cuda_stream), "pulse_qnet_act_select")
+        qrows = torch.zeros((n, 13), device=dev)
+        acts_q = torch.full((n,), -1, dtype=torch.long, device=dev)
+        _native.check(_native.lib().pulse_qnet_act(C.byref(net), states.data_ptr(), states.stride(0), n, seat.data_ptr(), 2, float(q.epsilon),
+                                                   q.seed, 4242, q.table_id0, acts_q.data_ptr(), qrows.data_ptr(), term.view(torch.uint8).data_ptr(), None,
+                                                   torch.cuda.current_stream().cuda_stream), "pulse_qnet_act")
+        torch.cuda.synchronize()
+        assert torch.equal(acts, acts_q)                                   # the Q output rides along without changing anything
+        W = (n + 127) // 128
+        out.append((acts.clone(), mask.clone(), scratch[nw * 256: nw * 256 + W].clone(), scratch[:W * 128].view(W, 128).clone(), qrows))
+    (a1, m1, c1, r1, q1), (a2, m2, c2, r2, q2) = out
+    assert torch.equal(m1, m2) and torch.equal(c1, c2)
+    keep = torch.arange(128, device=dev)[None, :] < c1[:, None]
+    assert torch.equal(r1[keep], r2[keep])
+    mine = seat == 2
+    assert int(mine.sum()) > n // 8 and bool((a1[~mine] == -1).all()) and bool((q1[~mine] == 0).all())
+    np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=0, atol=Q_TOL)
+    top2 = torch.topk(q2, 2, dim=1).values
+    clear = mine & ((top2[:, 0] - top2[:, 1]) > 4 * Q_TOL)
+    assert int(clear.sum()) > 0.9 * int(mine.sum())
+    assert torch.equal(a1[clear], a2[clear])
+    assert bool(((a1[mine] >= 0) & (a1[mine] < 13)).all())
+    # the actions follow the kernel's own Q rows exactly (first maximal index, the same epsilon draws)
+    from oracle import oracle as orc
+    want = np.full(n, -1, dtype=np.int64)
+    orc.qnet_act(q1.cpu().numpy(), seat.cpu().numpy(), 2, 0.15, 31, 4242, 123456, want)
+    np.testing.assert_array_equal(a1.cpu().numpy(), want)
