@@ -40,7 +40,7 @@ __device__ unsigned long long* g_qstamp_buf = nullptr;
 #endif
 
 #include "qnet_device.h"
-#include "qnet_rows4.h"
+#include "qnet_rows16.h"
 
 namespace {
 
@@ -836,10 +836,10 @@ __global__ __launch_bounds__(256) void qnet_adamw_kernel(const AdamArgs a) {
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
-// The masked action selection runs four rows per wavefront (qnet_rows4.h) where the observation rows and layer 1 are whole
-// float4s and the actions fit one DPP row; anything else -- and PULSE_ACT_TILES=1, the A/B switch of tools/bench_trainer.py --
-// takes the cooperative 32-row tiles.
-bool act_rows4_ok(const QNetArgs& a) {
+// The masked action selection runs sixteen rows per wavefront with the activations in registers (qnet_rows16.h) where the
+// observation rows and layer 1 are whole float4s and the actions fit one output tile; anything else -- and PULSE_ACT_TILES=1,
+// the A/B switch of the tests and tools/bench_trainer.py -- takes the cooperative 32-row tiles.
+bool act_rows16_ok(const QNetArgs& a) {
     const char* e = getenv("PULSE_ACT_TILES");                    // (read per call: the tests compare the two forms in one process)
     const bool tiles_forced = e && e[0] == '1';
     const PulseQNet& n = a.net;
@@ -898,20 +898,24 @@ int launch(const QNetArgs& a, void* stream) {
     const bool select = a.seat_idx != nullptr;
     const unsigned grid = select ? (unsigned)((a.n_rows + 63) / 64) : (unsigned)((a.n_rows + 31) / 32);
     hipStream_t st = (hipStream_t)stream;
-    if (select && act_rows4_ok(a)) {
-        const int slot = n.state_dim <= 40 ? 0 : 1;
-        const void* fns[2] = {reinterpret_cast<const void*>(&qnet_act_r4_kernel<10>), reinterpret_cast<const void*>(&qnet_act_r4_kernel<16>)};
-        const size_t lds_bytes = slot == 0 ? R4Lds<10>::bytes : R4Lds<16>::bytes;
-        static const void* attr_set[2] = {nullptr, nullptr};
+    if (select && act_rows16_ok(a)) {
+        const int cus = device_cus();
+        const bool wide = a.n_rows >= 1024 * cus;                 // large batches: windows of 1,024 candidates (~11 tiles for the 16 wavefronts)
+        const int slot = (n.state_dim <= 48 ? 0 : 1) + (wide ? 2 : 0);
+        const void* fns[4] = {reinterpret_cast<const void*>(&qnet_act_r16_kernel<3, 256>), reinterpret_cast<const void*>(&qnet_act_r16_kernel<4, 256>),
+                              reinterpret_cast<const void*>(&qnet_act_r16_kernel<3, 1024>), reinterpret_cast<const void*>(&qnet_act_r16_kernel<4, 1024>)};
+        const size_t lds_sizes[4] = {R16Lds<3, 256>::bytes, R16Lds<4, 256>::bytes, R16Lds<3, 1024>::bytes, R16Lds<4, 1024>::bytes};
+        static const void* attr_set[4] = {nullptr, nullptr, nullptr, nullptr};
         if (attr_set[slot] != fns[slot]) {
-            const hipError_t e = hipFuncSetAttribute(fns[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            const hipError_t e = hipFuncSetAttribute(fns[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sizes[slot]);
             if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_act: LDS size attribute");
             attr_set[slot] = fns[slot];
         }
-        const unsigned n_win = (unsigned)((a.n_rows + kR4Win - 1) / kR4Win);
+        const int win = wide ? 1024 : 256;
+        const unsigned n_win = (unsigned)((a.n_rows + win - 1) / win);
         void* params[1] = {const_cast<QNetArgs*>(&a)};
-        const hipError_t le = hipLaunchKernel(fns[slot], dim3(std::min(n_win, (unsigned)device_cus())), dim3(kR4Threads), params, lds_bytes, st);
-        if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_act (four rows per wavefront) launch");
+        const hipError_t le = hipLaunchKernel(fns[slot], dim3(std::min(n_win, (unsigned)cus)), dim3(kR16Threads), params, lds_sizes[slot], st);
+        if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_act (sixteen rows per wavefront) launch");
     } else if (select && n.state_dim > 64) {        // wider inputs than the cooperative tile's LDS image: one wavefront per tile
         if (vec) hipLaunchKernelGGL((qnet_kernel<true, true>), dim3(grid), dim3(64), 0, st, a); else hipLaunchKernelGGL((qnet_kernel<true, false>), dim3(grid), dim3(64), 0, st, a);
     } else if (select) {
@@ -1000,7 +1004,7 @@ int act_call(const PulseQNet* net, const float* states, int64_t row_stride, int3
         const size_t nw = (size_t)((n_rows + 255) / 256);
         a.tsel_rows = select_scratch; a.tsel_counts = select_scratch + nw * 256;
         // large batches, scratch permitting: list the learner's rows per window, then run them in full tiles (qnet_act_rows_kernel)
-        if (!act_rows4_ok(a) && n_rows >= kActTwoLaunchRows && select_words >= (int64_t)(nw * 517 + 512) && net->state_dim <= 64) {
+        if (!act_rows16_ok(a) && n_rows >= kActTwoLaunchRows && select_words >= (int64_t)(nw * 517 + 512) && net->state_dim <= 64) {
             a.asel_rows = select_scratch + nw * 259 + 512; a.asel_counts = a.asel_rows + nw * 256;
         }
     }

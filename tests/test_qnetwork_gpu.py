@@ -599,7 +599,7 @@ def test_act_policy_step_equals_act_then_policy_step(g, N, monkeypatch):
     lists + policy_step): after every step of three episodes the actions, the trainer's mask, the training launch's row
     lists, the observation / reward / done buffers and the whole table state are identical word for word, and so is the
     stop rule's count taken by the launch (scripts/Poker/trainGPU.py:79-86; Player.py:242-253; PokerGPU.py:527-633).  (The fused
-    launch runs the network on 32-row tiles; the stand-alone act launch is held to that form here -- its default, four rows per
+    launch runs the network on 32-row tiles; the stand-alone act launch is held to that form here -- its default, sixteen rows per
     wavefront, sums in another order and may break a near tie of two Q values the other way.)"""
     monkeypatch.setenv("PULSE_ACT_TILES", "1")
     from pulselib_amd.environments.Poker import PokerGPU
@@ -678,7 +678,7 @@ def test_act_policy_step_equals_act_then_policy_step(g, N, monkeypatch):
 
 
 def test_two_launch_action_selection_of_large_batches_equals_the_window_form(g, monkeypatch):
-    """The 32-row-tile forms of the masked action selection (what shapes outside the four-rows-per-wavefront kernel's run, and
+    """The 32-row-tile forms of the masked action selection (what shapes outside the sixteen-rows-per-wavefront kernel's run, and
     PULSE_ACT_TILES=1): from 262,144 rows on (and with the larger scratch) pulse_qnet_act_select first lists the learner's rows per window and
     then runs them in FULL 32-row tiles (qnet_act_rows_kernel) instead of one two-thirds-full tile per window of 128
     candidates: actions, the trainer's mask and the training launch's row lists must be those of the window form (forced
@@ -731,13 +731,13 @@ def test_two_launch_action_selection_of_large_batches_equals_the_window_form(g, 
     assert bool((a1[~mine] == -1).all()) and bool(((a1[mine] >= 0) & (a1[mine] < 13)).all()) and int(mine.sum()) > n // 8
 
 
-@pytest.mark.parametrize("n,case", [(70001, "s40"), (300, "s40"), (5000, "s64")])
-def test_four_rows_per_wavefront_action_selection_equals_the_tile_form(g, n, case, monkeypatch):
-    """pulse_qnet_act_select's default kernel (csrc/qnet_rows4.h: v_mfma_f32_4x4x1 with the A broadcast, four rows per
-    wavefront, the network in LDS) against the cooperative 32-row tiles (PULSE_ACT_TILES=1) on the same inputs: the trainer's
+@pytest.mark.parametrize("n,case", [(70001, "s40"), (300, "s40"), (5000, "s64"), (300001, "s40")])
+def test_sixteen_rows_per_wavefront_action_selection_equals_the_tile_form(g, n, case, monkeypatch):
+    """pulse_qnet_act_select's default kernel (csrc/qnet_rows16.h: sixteen rows per wavefront, v_mfma_f32_16x16x4 with the
+    activations in registers and the network in LDS) against the cooperative 32-row tiles (PULSE_ACT_TILES=1) on the same inputs: the trainer's
     mask and the training launch's row lists are identical, the Q rows agree to the order of the sums, and the actions are
     equal wherever the two best Q values of a row are further apart than that (Player.py:242-253; utils.py:113-119).  Ragged
-    sizes, windows full of the learner's rows (four passes of the 16 wavefronts) and windows without any."""
+    sizes, windows full of the learner's rows and windows without any; 300,000 rows take the windows of 1,024 candidates."""
     from pulselib_amd import _native
     dev = torch.device(DEV)
     rng = np.random.default_rng(n)

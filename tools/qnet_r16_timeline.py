@@ -1,7 +1,7 @@
-"""Where the four-rows-per-wavefront action selection (csrc/qnet_rows4.h: qnet_act_r4_kernel) spends its time: the diagnostic
+"""Where the sixteen-rows-per-wavefront action selection (csrc/qnet_rows16.h: qnet_act_r16_kernel) spends its time: the diagnostic
 build (`make -C pulselib_amd/csrc stamps`) stores the clock of lane 0 of EVERY wavefront at the phase boundaries; prints, per
 workgroup, the segments of wavefront 0 and when the last wavefront finished.  Read the SHARES (the stamps cost time).
-    python tools/qnet_r4_timeline.py [n_rows] [learner fraction]"""
+    python tools/qnet_r16_timeline.py [n_rows] [learner fraction]"""
 import ctypes as C
 import os
 import sys
@@ -29,7 +29,9 @@ s = torch.randn((N, 40), generator=g).to(dev)
 seat = (torch.rand((N,), generator=g) < frac).to(torch.int32).to(dev)       # seat 1 = the learner's
 acts = torch.zeros(N, dtype=torch.long, device=dev)
 mask = torch.zeros(N, dtype=torch.uint8, device=dev)
-n_blocks = min((N + 255) // 256, torch.cuda.get_device_properties(0).multi_processor_count)
+CUS = torch.cuda.get_device_properties(0).multi_processor_count
+WIN = 1024 if N >= 1024 * CUS else 256
+n_blocks = min((N + WIN - 1) // WIN, CUS)
 buf = torch.zeros((n_blocks, 16, 16), dtype=torch.int64, device=dev)
 net = q._net_struct(q.network)
 
