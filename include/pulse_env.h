@@ -417,7 +417,11 @@ int pulse_qnet_forward(const PulseQNet* net, const float* states, int64_t row_st
  * (action) of Philox4x32-10(seed, table_id0 + r, step), the stream pulse_poker_policy uses for scripted seats.
  * q_out NULL or fp32[n_rows, n_actions] (selected rows written).  row_mask_out (NULL or device uint8[n_rows], needs
  * seat_idx): row_mask_out[r] = (seat_idx[r] == q_seat) && !terminated[r] (terminated NULL = none) for EVERY row --
- * the trainer's `q_mask & ~terminated` (scripts/Poker/trainGPU.py:85), the row_mask of pulse_qnet_train_step. */
+ * the trainer's `q_mask & ~terminated` (scripts/Poker/trainGPU.py:85), the row_mask of pulse_qnet_train_step.
+ * Kernels: with seat_idx, state_dim a multiple of 4 in 13..64, n_actions <= 16 and 16-byte aligned rows (the Poker shapes)
+ * sixteen rows per wavefront with the activations in registers (csrc/qnet_rows16.h); otherwise cooperative 32-row tiles
+ * (csrc/qnet_device.h).  The two sum a layer's inputs in different orders: Q values agree to rounding (2e-5 at |Q| = O(1)),
+ * actions wherever the two best Q values of a row are further apart than that. */
 int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows,
                    const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
                    uint64_t table_id0, int64_t* actions, float* q_out, const uint8_t* terminated,
@@ -426,9 +430,9 @@ int pulse_qnet_act(const PulseQNet* net, const float* states, int64_t row_stride
  * THIS `states` as its states and THIS row_mask_out as its row_mask: the rows that call trains on (row_mask & seat
  * status ACTIVE / ALLIN) are known already, so their lists are written to the trainer's select_scratch here and the
  * training call skips its selection launch -- set PulseQNetTrain.select_from_act = 1 for that call (and only that one).
- * select_words: at least 259 per 256 rows + 512.  With 517 per 256 rows + 512 and 262,144 rows or more the selection runs
- * as TWO launches -- the windows only list the learner's rows (in the extra words), a second launch runs them in full
- * 32-row tiles (a window of 128 candidates holds ~21 of them: a third fewer tiles at 2,000,000 rows) -- same results. */
+ * select_words: at least 259 per 256 rows + 512.  (Shapes that take the 32-row-tile kernels, see pulse_qnet_act: with 517 per
+ * 256 rows + 512 and 262,144 rows or more the selection runs as TWO launches -- the windows only list the learner's rows (in
+ * the extra words), a second launch runs them in full tiles -- same results.) */
 int pulse_qnet_act_select(const PulseQNet* net, const float* states, int64_t row_stride, int32_t n_rows,
                           const int32_t* seat_idx, int32_t q_seat, float epsilon, uint64_t seed, uint64_t step,
                           uint64_t table_id0, int64_t* actions, const uint8_t* terminated, uint8_t* row_mask_out,

@@ -137,9 +137,7 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
     const int P = v.n_players, A = v.active_players;
     const bool seat = s < P, inA = s < A;
     const size_t row = (size_t)t * P + s;
-#if !PULSE_RESET_WIDE
     int32_t* dk = o.decks_out + (size_t)t * 52;
-#endif
 
     // decks: prefixed copy (:88-92) or rank-of-random-key shuffle == rand().argsort()+1 (:86).
     // The table's 16 lanes sit in one wavefront, LDS ops of a wavefront retire in order, so the
@@ -170,9 +168,9 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
         for (int c = s; c < 52; c += kLanes) deck_s[g][c] = src[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if !PULSE_RESET_WIDE
+    // (measured and dropped: the decks of the workgroup's 16 tables leaving as one block after the barrier below -- fewer store
+    // instructions, +1 us at every size: these stores overlap the rest of the kernel here, there they wait for the barrier)
     for (int c = s; c < 52; c += kLanes) dk[c] = deck_s[g][c];
-#endif
 
     // statistics of the episode that ends here (the caller's per-episode sums, trainGPU.py:96,104), before its flags go
     if (o.stats_out) {
@@ -288,9 +286,6 @@ __global__ __launch_bounds__(kBlock) void poker_reset_kernel(const PulsePokerVie
             v.equity_dirty[tt] = 1; v.prev_stacks[tt] = 0; v.prev_invested[tt] = 0;
         }
         for (int i = e; i < nw * 5; i += kBlock) v.board[t0w * 5 + i] = -1;            // :95
-        const int32_t* deck_flat = &deck_s[0][0];                                      // the workgroup's decks: one contiguous block
-        int32_t* dk = o.decks_out + (size_t)t0w * 52;
-        for (int i = e; i < nw * 52; i += nw * kLanes) dk[i] = deck_flat[i];          // (the threads of tables past the end have left: nw * 16 run)
     }
 #endif
     if (!v.pre_board) return;
