@@ -839,9 +839,10 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 // The masked action selection runs sixteen rows per wavefront with the activations in registers (qnet_rows16.h) where the
 // observation rows and layer 1 are whole float4s and the actions fit one output tile; anything else -- and PULSE_ACT_TILES=1,
 // the A/B switch of the tests and tools/bench_trainer.py -- takes the cooperative 32-row tiles.
+bool g_rows16_unavailable = false;       // the device refused the kernel's 147-156 KB of LDS once: the tiles from then on
 bool act_rows16_ok(const QNetArgs& a) {
     const char* e = getenv("PULSE_ACT_TILES");                    // (read per call: the tests compare the two forms in one process)
-    const bool tiles_forced = e && e[0] == '1';
+    const bool tiles_forced = (e && e[0] == '1') || g_rows16_unavailable;
     const PulseQNet& n = a.net;
     return !tiles_forced && a.seat_idx && a.actions && n.state_dim % 4 == 0 && n.state_dim >= 13 && n.state_dim <= 64 && n.n_actions <= 16 &&
            a.row_stride % 4 == 0 && aligned16(a.states) && aligned16(n.w1);
@@ -908,7 +909,11 @@ int launch(const QNetArgs& a, void* stream) {
         static const void* attr_set[4] = {nullptr, nullptr, nullptr, nullptr};
         if (attr_set[slot] != fns[slot]) {
             const hipError_t e = hipFuncSetAttribute(fns[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sizes[slot]);
-            if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_act: LDS size attribute");
+            if (e != hipSuccess) {                           // a device (partition) without that much LDS per workgroup: the tile kernels
+                (void)hipGetLastError();
+                g_rows16_unavailable = true;
+                return launch(a, stream);
+            }
             attr_set[slot] = fns[slot];
         }
         const int win = wide ? 1024 : 256;
