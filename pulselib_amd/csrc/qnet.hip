@@ -647,8 +647,6 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
     QSTAMP(9);
 }
 
-#include "qnet_train16.h"
-
 // Launch 2: flat gradient = sum of the used slices; scal[0] += its squared norm (one atomic per workgroup); workgroup 0
 // also totals the row count / squared TD error / reward and advances the optimizer step when there is something to learn.
 struct ReduceArgs {
@@ -690,21 +688,20 @@ __device__ __forceinline__ void adamw_one(const AdamArgs& a, int i, float g_sum,
 // of it; each then updates the parameters whose gradient sums it holds in registers.  Saves the third launch's dispatch
 // and its 4.7 us for a wait of about one.  Everything a workgroup reads that another wrote in this launch goes through
 // device-scope atomics (the norm, the counter): the per-XCD L2s are not coherent for plain loads.
-template <bool FUSED, bool L16 = false>      // L16: the slices are the 16-row training kernel's (qnet_train16.h)
+template <bool FUSED>
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs a, const AdamArgs w) {
-    constexpr int kStats = L16 ? kS16Stats : kSliceStats;
     __shared__ float red[4];
     __shared__ float4 part8[8][32];
     // 128 slice elements per workgroup as 32 float4 columns; the workgroups' slices are split between the eight 32-lane groups
     // of the workgroup (a fixed split: the sum order does not depend on timing), eight 16-byte loads in flight per thread.
     // One element per thread over all 256 slices was a chain of 32 dependent L2 round trips on 127 of the 256 CUs:
     // 17.5 us for 33 MB; this form 9-12 us.
-    static_assert(kSliceStats % 4 == 0 && kS16Stats % 4 == 0 && kSlicePitch % 4 == 0, "float4 columns");
+    static_assert(kSliceStats % 4 == 0 && kSlicePitch % 4 == 0, "float4 columns");
     const int grp = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int j0 = blockIdx.x * 128 + 4 * lane;                  // first of this thread's four slice elements
     const size_t pitch = (size_t)kSlicePitch;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (j0 < kStats) {
+    if (j0 < kSliceStats) {
         const float* p = a.partials + j0;
         // The slices that hold a gradient are those of workgroups 0 .. used - 1 (the training launch left the count): their
         // columns are loaded UNCONDITIONALLY, sixteen in flight per thread -- testing every slice's own flag first made each
@@ -730,11 +727,11 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     int pi = -1;
     if (threadIdx.x < 128) {
         const int j = blockIdx.x * 128 + threadIdx.x;
-        if (j < kStats) {
+        if (j < kSliceStats) {
             const int col = threadIdx.x >> 2, comp = threadIdx.x & 3;
 #pragma unroll
             for (int q = 0; q < 8; ++q) g += reinterpret_cast<const float*>(&part8[q][col])[comp];
-            const int i = L16 ? slice16_param(j, a.state_dim, a.n_actions) : slice_param(j, a.state_dim, a.n_actions);  // -1: a padding element of the slice layout
+            const int i = slice_param(j, a.state_dim, a.n_actions);  // -1: a padding element of the slice layout
             if (i >= 0 && i < a.n_params) { a.grad[i] = g; pi = i; } else g = 0.0f;
         }
     }
@@ -762,7 +759,7 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(const ReduceArgs 
     float rows = 0.0f, sq = 0.0f; double rew = 0.0;
     if ((FUSED || blockIdx.x == 0) && threadIdx.x < 64) {        // fused: every workgroup totals the row count itself
         for (int b = threadIdx.x; b < a.n_blocks; b += 64) {
-            const float* ps = a.partials + b * pitch + kStats;
+            const float* ps = a.partials + b * pitch + kSliceStats;
             rows += ps[0]; sq += ps[1]; rew += (double)ps[2];
         }
         if (blockIdx.x == 0 && a.reward_sum) for (int wdw = threadIdx.x; wdw < a.n_windows; wdw += 64) rew += (double)a.win_reward[wdw];
@@ -861,8 +858,7 @@ int device_cus() {
     }
     return cus[dev];
 }
-constexpr int kActTwoLaunchRows = 262144;
-constexpr int kTrain16Rows = 131072;           // from here on the training launch runs 16-row tiles, two workgroups per CU (qnet_train16.h)       // from here on the masked action selection lists first and runs full tiles second
+constexpr int kActTwoLaunchRows = 262144;       // from here on the masked action selection lists first and runs full tiles second
 
 // The fused reduce + AdamW launch is a meeting of all its workgroups inside one ordinary launch: it is only taken where the
 // device can hold the whole grid at once (asked once per device; a smaller part, e.g. a CPX partition, gets the two-launch
@@ -1080,8 +1076,7 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
     if (n_rows < 0) return pulse::fail(PULSE_EINVAL, "pulse_qnet_train_step: n_rows < 0");
     hipStream_t st = (hipStream_t)stream;
     const unsigned eg = (unsigned)((np + 255) / 256);
-    bool fused = false, tile16 = false;
-    int grid = 0;
+    bool fused = false;
     if (g_meet_gave_up) {
         const long long n = __atomic_load_n(g_meet_gave_up, __ATOMIC_ACQUIRE);
         if (n != g_meet_gave_up_seen) {
@@ -1131,50 +1126,25 @@ int train_launches(const PulseQNetTrain* t, const float* states, int64_t row_str
             if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
             attr_set[slot] = fns[slot];
         }
-        // Large batches (more 32-row tiles than CUs): tiles of 16 rows, two workgroups per CU (qnet_train16.h) -- where the rows
-        // and layer 1 are whole float4s.  PULSE_TRAIN_TILE=16 / 32 forces either (read per call: the tests compare them).
-        const char* tile_env = getenv("PULSE_TRAIN_TILE");
-        const bool vec16 = n.state_dim % 4 == 0 && row_stride % 4 == 0 && next_stride % 4 == 0 && aligned16(states) && aligned16(next_states) &&
-                           aligned16(t->params) && aligned16(t->target_params) && n.n_actions <= 16;
-        tile16 = vec16 && !four && ((tile_env && tile_env[0] == '1') || (!(tile_env && tile_env[0] == '3') && n_rows >= kTrain16Rows));
+        // persistent workgroups (157 KB of LDS: one per CU), one per possible tile of 32 rows at most
+        const int grid = std::min((n_rows + 31) / 32, (int)t->max_blocks);
         void* params[1] = {&a};
-        if (tile16) {
-            const int s16 = n.state_dim <= 48 ? 0 : 1;
-            const void* f16[2] = {reinterpret_cast<const void*>(&qnet_train16_kernel<3>), reinterpret_cast<const void*>(&qnet_train16_kernel<4>)};
-            static const void* attr16[2] = {nullptr, nullptr};
-            if (attr16[s16] != f16[s16]) {
-                const hipError_t e = hipFuncSetAttribute(f16[s16], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrain16LdsBytes);
-                if (e != hipSuccess) return pulse::fail_hip((int)e, "pulse_qnet_train_step: LDS size attribute");
-                attr16[s16] = f16[s16];
-            }
-            grid = std::min(std::min((n_rows + 15) / 16, (int)t->max_blocks), 2 * device_cus());
-            const hipError_t le = hipLaunchKernel(f16[s16], dim3((unsigned)grid), dim3(256), params, kTrain16LdsBytes, st);
-            if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_train_step (16-row tiles) launch");
-        } else {
-            // persistent workgroups (157 KB of LDS: one per CU), one per possible tile of 32 rows at most
-            grid = std::min(std::min((n_rows + 31) / 32, (int)t->max_blocks), device_cus());
-            const hipError_t le = hipLaunchKernel(fns[slot], dim3((unsigned)grid), dim3(four ? 256 : 512), params, kTrainLdsBytes, st);
-            if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_train_step launch");
-        }
+        const hipError_t le = hipLaunchKernel(fns[slot], dim3((unsigned)grid), dim3(four ? 256 : 512), params, kTrainLdsBytes, st);
+        if (le != hipSuccess) return pulse::fail_hip((int)le, "pulse_qnet_train_step launch");
     ReduceArgs r{};
     r.partials = t->partials; r.n_blocks = grid; r.n_params = np; r.state_dim = n.state_dim; r.n_actions = n.n_actions;
     r.grad = t->grad; r.scal = t->stats;
     r.step = apply ? (long long*)t->step : nullptr;        // gradients only: the caller advances the step after its all-reduce
     r.reward_sum = reward_sum; r.win_reward = win_reward; r.n_windows = n_windows; r.meet = a.meet;
     AdamArgs b = adam_args(t, np);
-    const unsigned rg = (unsigned)(((tile16 ? kS16Stats : kSliceStats) + 127) / 128);
+    const unsigned rg = (unsigned)((kSliceStats + 127) / 128);
     // one GPU: AdamW rides in the reduce launch -- where the whole grid fits the device at once
     fused = apply && !t->separate_apply && fused_apply_fits(rg);
     r.wait_ticks = t->meet_wait_ticks > 0 ? (long long)t->meet_wait_ticks : 500000000ll;     // 5 s of the 100 MHz clock
     r.extra_arrivals = t->debug_meet_extra > 0 ? (unsigned)t->debug_meet_extra : 0u;
     r.gave_up = g_meet_gave_up;
-    if (tile16) {
-        if (fused) hipLaunchKernelGGL((qnet_grad_reduce_kernel<true, true>), dim3(rg), dim3(256), 0, st, r, b);
-        else hipLaunchKernelGGL((qnet_grad_reduce_kernel<false, true>), dim3(rg), dim3(256), 0, st, r, b);
-    } else {
-        if (fused) hipLaunchKernelGGL((qnet_grad_reduce_kernel<true, false>), dim3(rg), dim3(256), 0, st, r, b);
-        else hipLaunchKernelGGL((qnet_grad_reduce_kernel<false, false>), dim3(rg), dim3(256), 0, st, r, b);
-    }
+    if (fused) hipLaunchKernelGGL(qnet_grad_reduce_kernel<true>, dim3(rg), dim3(256), 0, st, r, b);
+    else hipLaunchKernelGGL(qnet_grad_reduce_kernel<false>, dim3(rg), dim3(256), 0, st, r, b);
     }
     if (apply && !fused && (n_rows > 0 || !grads)) {
         const AdamArgs b = adam_args(t, np);

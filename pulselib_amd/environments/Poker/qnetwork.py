@@ -25,7 +25,7 @@ import torch.nn as nn
 from ... import _native
 
 HIDDEN = (128, 128, 64, 32)      # Player.py:189-201
-TRAIN_BLOCKS = 512               # gradient slices = persistent workgroups of the training launch: one per CU of an MI355X for 32-row tiles, two for 16-row tiles
+TRAIN_BLOCKS = 256               # persistent workgroups of the training kernel: one per CU of an MI355X
 
 
 def build_network(state_dim: int, action_dim: int) -> nn.Sequential:

@@ -219,17 +219,11 @@ def _batch(n, seed, state_dim=40):
                 rewards=(rng.standard_normal(n) * 3).astype(np.float32), dones=rng.random(n) < 0.3, row_mask=rng.random(n) < 0.6)
 
 
-TILES = pytest.mark.parametrize("tile", ["32", "16"])     # the training launch's two forms (PULSE_TRAIN_TILE: 32-row tiles, one workgroup
-                                                           # per CU; 16-row tiles, two -- the default from 131,072 rows on, csrc/qnet_train16.h)
-
-
-@TILES
 @pytest.mark.parametrize("n,drop,case", [(1000, True, "s40"), (1000, False, "s40"), (37, True, "s40"), (70000, True, "s40"),
                                          (1500, True, "s27")])
-def test_native_train_step_matches_oracle(g, n, drop, case, tile, monkeypatch):
+def test_native_train_step_matches_oracle(g, n, drop, case):
     """Three native updates against the oracle's scalar restatement (same dropout draws, same AdamW arithmetic):
     row count, loss, gradient norm and the parameters after every step; target sync at update_freq."""
-    monkeypatch.setenv("PULSE_TRAIN_TILE", tile)
     from oracle import oracle as orc
     q = _qnet(g, case, seed=77, table_id0=5_000_000_000)        # s27: the scalar-load (unaligned state_dim) variants of the kernels
     sd = q.state_dim
@@ -261,11 +255,9 @@ def test_native_train_step_matches_oracle(g, n, drop, case, tile, monkeypatch):
     assert np.abs(_flat(q.target_network) - _flat(q.network)).max() == 0        # synced at optimizer step 2
 
 
-@TILES
-def test_native_gradient_matches_oracle_and_torch_autograd(g, tile, monkeypatch):
+def test_native_gradient_matches_oracle_and_torch_autograd(g):
     """The raw gradient (before mean / clip / AdamW) of one batch: native kernel vs oracle vs torch autograd of the
     reference's loss (dropout off so that torch can be compared)."""
-    monkeypatch.setenv("PULSE_TRAIN_TILE", tile)
     from oracle import oracle as orc
     q = _qnet(g, "s40", seed=5)
     q.network.eval()
@@ -399,12 +391,10 @@ def test_native_training_reduces_td_error_on_a_fixed_batch(g):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
-@TILES
 @pytest.mark.parametrize("net", ["s40", "s64"])
-def test_native_train_step_writes_only_inside_its_buffers(g, net, tile, monkeypatch):
+def test_native_train_step_writes_only_inside_its_buffers(g, net):
     """Guard words either side of the gradient, the moments and the slice scratch stay untouched by a training step (the
     slice layout has padding elements that map to no parameter: they must be dropped, not written at index -1)."""
-    monkeypatch.setenv("PULSE_TRAIN_TILE", tile)
     if net == "s64":
         from pulselib_amd.environments.Poker import PokerQNetwork
         torch.manual_seed(64)
@@ -439,10 +429,8 @@ def test_native_train_step_writes_only_inside_its_buffers(g, net, tile, monkeypa
     assert float(nat["grad"].abs().sum()) > 0.0
 
 
-@TILES
-def test_native_train_step_folds_trainer_bookkeeping(g, tile, monkeypatch):
+def test_native_train_step_folds_trainer_bookkeeping(g):
     """terminated |= dones and reward_sum += rewards[row_mask] ride along with the training launches (trainGPU.py:86,96)."""
-    monkeypatch.setenv("PULSE_TRAIN_TILE", tile)
     q = _qnet(g, "s40", seed=2)
     n = 5000
     b = _batch(n, 11)
@@ -543,13 +531,11 @@ def test_native_kernels_empty_and_full_selections(g):
     assert np.array_equal(_flat(q.network), before)                                      # zero rows: nothing launched, nothing moves
 
 
-@TILES
 @pytest.mark.parametrize("n", [700, 5000, 70001])
-def test_row_lists_from_the_act_launch_equal_the_selection_launch(g, n, tile, monkeypatch):
+def test_row_lists_from_the_act_launch_equal_the_selection_launch(g, n):
     """act_into(select_for_training=True) writes the training launch's row lists (128-row windows) itself; the lists of the
     selection launch (256-row windows) hold the same rows in the same order, so the two ways train the same tiles and
     leave bit-identical parameters; `terminated |= dones` equal, the episode reward equal up to its summation order."""
-    monkeypatch.setenv("PULSE_TRAIN_TILE", tile)
     rng = np.random.default_rng(n)
     b = _batch(n, 17)
     b["states"][:, 12] = rng.integers(0, 4, n)                   # seat status: a good part of the rows is not trainable
