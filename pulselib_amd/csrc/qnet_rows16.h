@@ -17,7 +17,8 @@
 //
 // Measured and replaced on the way (same interface, profiles/README.md): four rows per wavefront on v_mfma_f32_4x4x1 with the
 // A broadcast (tools/probes/mfma4x4_probe.hip): one more transpose per layer and, decisive, a two-pass MFMA leaves the SIMD
-// no issue slot for other work (cost = 8 cycles x MFMAs + 4 x vector instructions, 1.8 K cycles per row against 1.2 K here).
+// no issue slot for other work (cost = 8 cycles x MFMAs + 4 x vector instructions: 1.8 K cycles per row against 1.6 K here) -- no
+// faster than the 32-row tiles at 65,536 tables (22.6 us; this form 18.8) and 395 against 314 us at 2,000,000.
 // Not part of the ABI.
 #pragma once
 #include "qnet_device.h"
