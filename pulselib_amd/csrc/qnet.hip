@@ -194,6 +194,13 @@ constexpr int kSliceStats = kSliceBias + 384, kSlicePitch = kSliceStats + 4;
 // accumulated yet); delta in D, a_{l-1} in Ap; bsum: this tile's db rows of tile ot
 __device__ __forceinline__ void dw_accum(const float* __restrict__ D, const float* __restrict__ Ap, float* __restrict__ slice, int blk,
                                          int ot, int it, int c, int h, bool first, float* bsum) {
+    // registers 4q .. 4q+3 of all 64 lanes form one contiguous KB of the slice: a store instruction writes whole lines.  The
+    // block's old values are asked for FIRST (not after the MFMAs, where every call waited out their round trip: with ~20 tiles
+    // per workgroup at 2,000,000 tables the slices live in the Infinity Cache, not in L2)
+    float4* dst = reinterpret_cast<float4*>(slice + (size_t)blk * 1024) + (c + 32 * h);
+    float4 old[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { old[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); if (!first) old[q] = dst[64 * q]; }
     float ad[16], ap[16]; float bs = 0.0f;
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) { ad[s2] = D[(32 * ot + c) * kLd + 2 * s2 + h]; ap[s2] = Ap[(32 * it + c) * kLd + 2 * s2 + h]; }
@@ -204,14 +211,9 @@ __device__ __forceinline__ void dw_accum(const float* __restrict__ D, const floa
     f32x16 acc = zero16();
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s2], ap[s2], acc, 0, 0, 0);
-    // registers 4q .. 4q+3 of all 64 lanes form one contiguous KB of the slice: a store instruction writes whole lines
-    float4* dst = reinterpret_cast<float4*>(slice + (size_t)blk * 1024) + (c + 32 * h);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        if (!first) { const float4 o = dst[64 * q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        dst[64 * q] = v;
-    }
+    for (int q = 0; q < 4; ++q)
+        dst[64 * q] = make_float4(acc[4 * q] + old[q].x, acc[4 * q + 1] + old[q].y, acc[4 * q + 2] + old[q].z, acc[4 * q + 3] + old[q].w);
 }
 
 // flat parameter index (order w1,b1,...,w5,b5) of slice element j, or -1 for a padding element
