@@ -500,23 +500,24 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
         }
     }
     const int W = 1 << a.win_shift;
-    const int n_windows = (a.n_rows + W - 1) >> a.win_shift, per = (n_windows + 255) / 256;
+    // (512 first positions, one per thread: a column's walk along its thread's windows below is half as long as with 256 -- at
+    // 2,000,000 tables 31 windows instead of 62, a dependent load each)
+    const int n_windows = (a.n_rows + W - 1) >> a.win_shift, per = (n_windows + 511) / 512;
     int* chunk = reinterpret_cast<int*>(lds + CoopLds::List);
     int T;
     {
         int mine = 0;
-        if (threadIdx.x < 256) for (int j = 0; j < per; ++j) { const int w = threadIdx.x * per + j; mine += w < n_windows ? a.sel_counts[w] : 0; }
+        for (int j = 0; j < per; ++j) { const int w = threadIdx.x * per + j; mine += w < n_windows ? a.sel_counts[w] : 0; }
         int incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); incl += lane >= off ? o : 0; }
-        int* wtot = chunk + 257;
-        if (lane == 63 && wv < 4) wtot[wv] = incl;
+        int* wtot = chunk + 512;
+        if (lane == 63) wtot[wv] = incl;
         __syncthreads();
-        int base = 0;
+        int base = 0; T = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) base += i < wv ? wtot[i] : 0;
-        if (threadIdx.x < 256) chunk[threadIdx.x] = base + incl - mine;
-        T = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+        for (int i = 0; i < 8; ++i) { const int n = wtot[i]; base += i < wv ? n : 0; T += n; }
+        chunk[threadIdx.x] = base + incl - mine;
         __syncthreads();
     }
     const int G = (int)gridDim.x;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
             const int p = lo + c;
             int t = 0;
 #pragma unroll
-            for (int s = 128; s >= 1; s >>= 1) t += (chunk[t + s] <= p) ? s : 0;
+            for (int s = 256; s >= 1; s >>= 1) t += (chunk[t + s] <= p) ? s : 0;
             int w = t * per, acc = chunk[t], cnt = a.sel_counts[w];
             while (p >= acc + cnt) { acc += cnt; ++w; cnt = a.sel_counts[w]; }
             rowc = a.sel_rows[((size_t)w << a.win_shift) + (p - acc)];

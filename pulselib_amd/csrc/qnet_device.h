@@ -213,7 +213,7 @@ struct CoopLds {                 // offsets in floats into the dynamic LDS block
                          P = A4 + 32 * kLd,                    // 2 x (3 x 16 x 64) partial sums (two networks in flight in training)
                          List = P + 2 * 3 * 16 * 64,           // act: row ids of the window + wavefront counts; training: first positions of
                                                                // the threads' windows (256) + counts
-                         Tgt = List + 264,                     // 32 words: max_a' Q_target per column, wavefront sums at the end
+                         Tgt = List + 520,                     // (List: up to 512 first positions + 8 totals) 32 words: max_a' Q_target per column, wavefront sums at the end
                          EndEval = Tgt + 32,
                          G1 = EndEval, G2 = G1 + 128 * kLd, G3 = G2 + 128 * kLd, G4 = G3 + 64 * kLd,
                          Da = G4 + 32 * kLd, Db = Da + 128 * kLd, EndTrain = Db + 128 * kLd;
