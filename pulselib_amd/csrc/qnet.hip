@@ -525,15 +525,9 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
     // as with 32), and every workgroup at most one more tile than any other
     const int n_tiles = (T + 31) / 32;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.meet[kMeetUsed] = (unsigned)min(n_tiles, G);      // workgroups 0 .. n_tiles - 1 hold a gradient slice (the reduce launch sums exactly those)
-    for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
-        const bool first = !used;
-        used = true;
-        int opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        float* part_t = part + opaque;
-        int c = c0, h = h0;
-        asm volatile("" : "+v"(c), "+v"(h));
-        const int wq = wv & 3, grp = wv >> 2;
+    // column c of tile ti = position lo + c of the batch's listed rows: its thread's first position by bisection, then along that
+    // thread's windows (a dependent load each)
+    auto tile_row = [&](int ti, int c) -> int {
         const int lo = (int)((long long)ti * T / n_tiles), hi = (int)((long long)(ti + 1) * T / n_tiles);
         int rowc = -1;
         if (lo + c < hi) {
@@ -545,6 +539,25 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
             while (p >= acc + cnt) { acc += cnt; ++w; cnt = a.sel_counts[w]; }
             rowc = a.sel_rows[((size_t)w << a.win_shift) + (p - acc)];
         }
+        return rowc;
+    };
+    // The NEXT tile's rows are looked up by wavefront 7 while it has nothing to do (the layer-5 backward phase runs on two
+    // wavefronts) and their observation rows are asked for by everybody in the layer-4 phase: with ~20 tiles per workgroup the
+    // walk and the gather's round trip were 5 % of a tile, in front of its first layer.
+    int* const next_rows = reinterpret_cast<int*>(Tg);           // (free between delta_5 and the next tile's max Q_target)
+    int rowc_next = blockIdx.x < n_tiles ? tile_row((int)blockIdx.x, c0) : -1;
+    float xpre[8];
+    bool have_pre = false;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += G) {
+        const bool first = !used;
+        used = true;
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        float* part_t = part + opaque;
+        int c = c0, h = h0;
+        asm volatile("" : "+v"(c), "+v"(h));
+        const int wq = wv & 3, grp = wv >> 2;
+        const int rowc = rowc_next;
         const bool live = rowc >= 0;
         const int rw = max(rowc, 0);
         const uint64_t gid = a.table_id0 + (uint64_t)rw;
@@ -553,8 +566,11 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
         // group 0: the target network on s' (x' and a'_2, a'_4 in Db, a'_1 and a'_3 in Da); group 1: the network on s
         float w1r[NK1][4];
         load_layer<VEC, NK1>(w1r, grp ? n : a.tgt, 0, 32 * wq + c, h, 0, (K1 + 7) & ~7);
-        if (grp) coop_load_rows<VEC>(Xs, a.states, a.stride, K1, rowc, wq, c, h);
-        else coop_load_rows<VEC>(Db, a.next_states, a.next_stride, K1, rowc, wq, c, h);
+        if (!have_pre) {
+            if (grp) coop_fetch_rows<VEC>(xpre, a.states, a.stride, K1, rowc, wq, h);
+            else coop_fetch_rows<VEC>(xpre, a.next_states, a.next_stride, K1, rowc, wq, h);
+        }
+        coop_store_rows(grp ? Xs : Db, xpre, wq, c, h);
         const float row_done = (live && a.dones[rw]) ? 1.0f : 0.0f, row_reward = live ? a.rewards[rw] : 0.0f;
         const int act = live ? (int)a.actions[rw] : -1;
         f32x16 qv;
@@ -590,8 +606,16 @@ __global__ __launch_bounds__(512) void qnet_train8_kernel(const TrainArgs a) {
         // and weights held a phase ahead do not fit 256 registers next to the phase's own operands)
         if (wv == 0) dw_accum(Da, A4, part_t, kSliceBlk5, 0, 0, c, h, first, &b5);
         if (wv == 1) { float wb5[16]; back_load<32>(wb5, net_w(n, 4), A, 32, 0, c, h); back_mul<32>(wb5, 0, Da, G4, Db, c, h); }
+        const bool more = ti + G < n_tiles;
+        if (wv == 7 && more) { const int r = tile_row(ti + G, c); if (h == 0) next_rows[c] = r; }
         lds_barrier();
         QSTAMP(4);
+        rowc_next = more ? next_rows[c] : -1;
+        have_pre = more;
+        if (more) {
+            if (grp) coop_fetch_rows<VEC>(xpre, a.states, a.stride, K1, rowc_next, wq, h);
+            else coop_fetch_rows<VEC>(xpre, a.next_states, a.next_stride, K1, rowc_next, wq, h);
+        }
         // layer 4 (delta_4 in Db): dW4 blocks on wavefronts 0, 1 | delta_3 tiles on 2, 3 -> Da
         if (wv == 0) dw_accum(Db, A3, part_t, kSliceBlk4 + 0, 0, 0, c, h, first, &b4);
         if (wv == 1) dw_accum(Db, A3, part_t, kSliceBlk4 + 1, 0, 1, c, h, first, nullptr);

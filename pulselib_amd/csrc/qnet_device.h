@@ -432,11 +432,9 @@ __device__ __forceinline__ void coop_epilogue8(const f32x16& acc, const float (&
 // 32 rows of `x` (row ids per column in `rowc`, < 0 = padding) -> Xs[k][column], zero above state_dim; all 4 wavefronts.
 // VEC (16-byte aligned rows of a multiple of 8 inputs): a lane's 8 inputs are two 16-byte loads.
 template <bool VEC>
-__device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const float* __restrict__ x, long long stride, int K1, int rowc,
-                                               int wv, int c, int h) {
+__device__ __forceinline__ void coop_fetch_rows(float (&v)[8], const float* __restrict__ x, long long stride, int K1, int rowc, int wv, int h) {
     const float* xr = x + (size_t)max(rowc, 0) * stride;
     const int k0 = 16 * wv + 8 * h;
-    float v[8];
     if (VEC) {
         float4 lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hi = lo;
         if (rowc >= 0 && k0 < K1) { lo = *reinterpret_cast<const float4*>(xr + k0); hi = *reinterpret_cast<const float4*>(xr + k0 + 4); }
@@ -445,8 +443,18 @@ __device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (rowc >= 0 && k0 + j < K1) ? xr[k0 + j] : 0.0f;
     }
+}
+__device__ __forceinline__ void coop_store_rows(float* __restrict__ dst, const float (&v)[8], int wv, int c, int h) {
+    const int k0 = 16 * wv + 8 * h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dst[(k0 + j) * kLd + c] = v[j];
+}
+template <bool VEC>
+__device__ __forceinline__ void coop_load_rows(float* __restrict__ dst, const float* __restrict__ x, long long stride, int K1, int rowc,
+                                               int wv, int c, int h) {
+    float v[8];
+    coop_fetch_rows<VEC>(v, x, stride, K1, rowc, wv, h);
+    coop_store_rows(dst, v, wv, c, h);
 }
 
 // Training: the target network on s' (eval) and the network on s (train mode) taken through the layers TOGETHER -- every
