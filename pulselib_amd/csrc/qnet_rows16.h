@@ -179,19 +179,28 @@ __global__ __launch_bounds__(kR16Threads) void qnet_act_r16_kernel(const QNetArg
     const int K1 = a.net.state_dim, A = a.net.n_actions;
     R16STAMP(0);
     const int n_win = (a.n_rows + WIN - 1) / WIN;
-    // a window's candidate words (seat index, terminated flag, seat status) are loaded one window ahead: the first window's
-    // arrive while the weights are copied, the next one's while this one's rows go through the layers
-    int c_seat = -1; bool c_term = false; float c_status = 1.0f;
-    auto load_candidates = [&](int win) {
+    // A window's candidate words are loaded ahead of its turn: seat index and terminated flag TWO windows ahead, the seat status
+    // (observation column 12) ONE window ahead and only for the learner's live rows -- read for every candidate it pulled every
+    // line of the observation through the chip (320 MB at 2,000,000 tables, a quarter of the launch).  The first window's words
+    // arrive while the weights are copied.
+    const int stride_w = (int)gridDim.x;
+    int c_seat = -1, n_seat = -1; bool c_term = false, n_term = false; float c_status = 1.0f;
+    auto load_seat = [&](int win, int& seat, bool& term) {
         const int row = win * WIN + tid;
-        c_seat = -1; c_term = false; c_status = 1.0f;
+        seat = -1; term = false;
         if (tid < WIN && win < n_win && row < a.n_rows) {
-            c_seat = a.seat_idx[row];
-            if (a.terminated) c_term = a.terminated[row] != 0;
-            if (a.tsel_counts) c_status = a.states[(size_t)row * a.row_stride + 12];
+            seat = a.seat_idx[row];
+            if (a.terminated) term = a.terminated[row] != 0;
         }
     };
-    load_candidates((int)blockIdx.x);
+    auto load_status = [&](int win, int seat, bool term) -> float {
+        const int row = win * WIN + tid;
+        const bool inside = tid < WIN && win < n_win && row < a.n_rows;
+        return (a.tsel_counts && inside && seat == a.q_seat && !term) ? a.states[(size_t)row * a.row_stride + 12] : 1.0f;
+    };
+    load_seat((int)blockIdx.x, c_seat, c_term);
+    load_seat((int)blockIdx.x + stride_w, n_seat, n_term);
+    c_status = load_status((int)blockIdx.x, c_seat, c_term);
     {
         float4 v1[R16Part<8, MT1>::N], v2[R16Part<8, 8>::N], v3[R16Part<4, 8>::N], v4[R16Part<2, 4>::N], v5[R16Part<1, 2>::N];
         r16_fill_load<8, MT1>(v1, a.net.w1, 128, K1);
@@ -225,7 +234,10 @@ __global__ __launch_bounds__(kR16Threads) void qnet_act_r16_kernel(const QNetArg
         const bool tsel = a.tsel_counts && live && (c_status == 0.0f || c_status == 2.0f);
         const unsigned long long m = __ballot(sel), tm = __ballot(tsel);
         if (wv < NWV && lane == 0) { wcount[wv] = __popcll(m); tcount[wv] = __popcll(tm); }
-        load_candidates(win + (int)gridDim.x);
+        // next window: its status words (its seat words arrived a window ago); the window after: its seat words
+        const float nn_status = load_status(win + stride_w, n_seat, n_term);
+        int nn_seat; bool nn_term;
+        load_seat(win + 2 * stride_w, nn_seat, nn_term);
         R16STAMP(1);
         __syncthreads();                       // (also: every wavefront has read its rows of the previous window's list)
         R16STAMP(2);
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(kR16Threads) void qnet_act_r16_kernel(const QNetArg
             }
             R16STAMP(6);
         }
+        c_seat = n_seat; c_term = n_term; c_status = nn_status; n_seat = nn_seat; n_term = nn_term;
     }
     R16STAMP(7);
 }
